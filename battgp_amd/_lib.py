@@ -1,0 +1,80 @@
+"""ctypes binding of libbattgp.so (the C-ABI declared in include/battgp.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  If the shared object is
+missing or does not export the declared symbols, loading fails loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbattgp.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+handle_p = C.c_void_p
+
+# name -> (restype, argtypes); must list EVERY symbol of include/battgp.h
+SIGNATURES = {
+    "bgp_version": (C.c_int, []),
+    "bgp_create": (C.c_int, [C.POINTER(handle_p), C.c_int]),
+    "bgp_destroy": (None, [handle_p]),
+    "bgp_last_error": (C.c_char_p, [handle_p]),
+    "bgp_set_kernel": (C.c_int, [handle_p, C.c_int, c_double_p, C.c_int]),
+    "bgp_set_options": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_double, C.c_int]),
+    "bgp_fit": (C.c_int, [handle_p, c_double_p, c_double_p, C.c_int64, C.c_int, c_double_p, c_double_p]),
+    "bgp_fit_dev": (C.c_int, [handle_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, c_double_p, c_double_p]),
+    "bgp_refit": (C.c_int, [handle_p, c_double_p, C.c_int, c_double_p, c_double_p]),
+    "bgp_predict": (C.c_int, [handle_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_double]),
+    "bgp_predict_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double]),
+    "bgp_predict_cov": (C.c_int, [handle_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
+    "bgp_kernel_matrix": (C.c_int, [handle_p, c_double_p, C.c_int64, c_double_p, C.c_int64, C.c_int, c_double_p]),
+    "bgp_get_alpha": (C.c_int, [handle_p, c_double_p]),
+    "bgp_residuals": (C.c_int, [handle_p, C.c_int, c_double_p]),
+    "bgp_phase_times": (C.c_int, [handle_p, c_double_p, C.c_int]),
+    "bgp_device_bytes": (C.c_int64, [handle_p]),
+    "bgp_potrf_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, c_int_p]),
+    "bgp_gemm_nt_sub_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int],
+    ),
+    "bgp_fill_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double],
+    ),
+}
+
+# indices of bgp_phase_times (BGP_T_* in battgp.h)
+T_H2D, T_FILL, T_POTRF, T_SOLVE, T_CROSS, T_VAR, T_D2H, T_TRAIL, T_TRAIL_FLOP, T_FILL_BYTES = range(10)
+T_COUNT = 10
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libbattgp.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m battgp_amd.build` "
+            "(hipcc --offload-arch=gfx950).  battgp_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise ImportError(f"libbattgp.so does not export `{name}`") from exc
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(arr):
+    """numpy fp64 C-contiguous array -> double*"""
+    return arr.ctypes.data_as(c_double_p)

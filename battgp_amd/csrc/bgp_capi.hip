@@ -1,0 +1,715 @@
+// Host-side drivers (blocked Cholesky, triangular solves, predict) and the C-ABI of
+// libbattgp.so.  See include/battgp.h for the contract of every entry point.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "bgp_internal.h"
+
+static thread_local std::string g_create_err;
+
+int bgp_fail(bgp_handle* h, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  else g_create_err = buf;
+  return code;
+}
+
+namespace {
+
+inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+
+int dev_alloc(bgp_handle* h, double** p, int64_t n_doubles) {
+  *p = nullptr;
+  if (n_doubles <= 0) return 0;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)n_doubles * sizeof(double));
+  if (e != hipSuccess) {
+    *p = nullptr;
+    (void)hipGetLastError();
+    return bgp_fail(h, -3, "hipMalloc of %.3f GB failed: %s", n_doubles * 8.0 / 1e9, hipGetErrorString(e));
+  }
+  h->bytes += n_doubles * 8;
+  return 0;
+}
+
+void dev_free(bgp_handle* h, double** p, int64_t n_doubles) {
+  if (*p) {
+    (void)hipFree(*p);
+    h->bytes -= n_doubles * 8;
+    *p = nullptr;
+  }
+}
+
+int expected_nhyp(int kid, int D) {
+  switch (kid) {
+    case BGP_KERNEL_BATTGP: return 3 + (D - 1);
+    case BGP_KERNEL_SCALED_RBF: return 3;
+    case BGP_KERNEL_MATERN32:
+    case BGP_KERNEL_ARD_RBF: return 2 + D;
+  }
+  return -1;
+}
+
+int make_fill_params(bgp_handle* h, int D, double extra_diag, FillParams* p) {
+  if (!h->kernel_set) return bgp_fail(h, -1, "bgp_set_kernel has not been called");
+  if (D < 1 || D > BGP_MAX_DIM) return bgp_fail(h, -1, "D=%d outside 1..%d", D, BGP_MAX_DIM);
+  if (h->kernel_id == BGP_KERNEL_BATTGP && D < 2)
+    return bgp_fail(h, -1, "the battgp kernel needs a time column and at least one RBF column");
+  if (expected_nhyp(h->kernel_id, D) != h->nhyp)
+    return bgp_fail(h, -1, "kernel %d with D=%d expects %d hyper-parameters, got %d", h->kernel_id, D,
+                    expected_nhyp(h->kernel_id, D), h->nhyp);
+  memset(p, 0, sizeof(*p));
+  p->kid = h->kernel_id;
+  p->D = D;
+  p->noise = h->hyp[0] + extra_diag;
+  const double rs2 = 0.70710678118654752440;  // 1/sqrt(2)
+  switch (h->kernel_id) {
+    case BGP_KERNEL_BATTGP:
+      p->s0 = h->hyp[1];
+      p->s1 = h->hyp[2];
+      p->scale[0] = 1.0;
+      for (int d = 1; d < D; ++d) p->scale[d] = rs2 / h->hyp[2 + d];
+      break;
+    case BGP_KERNEL_SCALED_RBF:
+      p->s0 = h->hyp[1];
+      for (int d = 0; d < D; ++d) p->scale[d] = rs2 / h->hyp[2];
+      break;
+    case BGP_KERNEL_MATERN32:
+      p->s0 = h->hyp[1];
+      for (int d = 0; d < D; ++d) p->scale[d] = 1.7320508075688772935 / h->hyp[2 + d];
+      break;
+    case BGP_KERNEL_ARD_RBF:
+      p->s0 = h->hyp[1];
+      for (int d = 0; d < D; ++d) p->scale[d] = rs2 / h->hyp[2 + d];
+      break;
+  }
+  return 0;
+}
+
+struct PhaseTimer {
+  bgp_handle* h;
+  hipStream_t st;
+  int slot;
+  bool accumulate;
+  PhaseTimer(bgp_handle* h_, hipStream_t st_, int slot_, bool acc = false)
+      : h(h_), st(st_), slot(slot_), accumulate(acc) {
+    (void)hipEventRecord(h->ev_a, st);
+  }
+  // must be called after the work is enqueued; synchronises the stream
+  int stop() {
+    BGP_HIP(h, hipEventRecord(h->ev_b, st));
+    BGP_HIP(h, hipEventSynchronize(h->ev_b));
+    float ms = 0.f;
+    BGP_HIP(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    if (accumulate) h->times[slot] += ms;
+    else h->times[slot] = ms;
+    return 0;
+  }
+};
+
+// ---- blocked right-looking Cholesky (lower, in place), n multiple of 64 -------------------
+//  outer panels of width NB: inside a panel, 64-wide steps {tile potrf+inverse, TRSM by the
+//  inverse (MFMA), rank-64 update of the rest of the panel (MFMA)}; then one rank-NB SYRK
+//  update of the whole trailing matrix (MFMA) - the kernel that carries ~all the flops.
+int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t lda, double* inv, int* dinfo,
+                 int* info_out, bool time_trailing) {
+  const int64_t NB = h->nb_outer;
+  BGP_HIP(h, hipMemsetAsync(dinfo, 0, sizeof(int), st));
+  size_t ev_used = 0;
+  double trail_flop = 0.0;
+  int step = 0;
+  *info_out = 0;
+  for (int64_t K0 = 0; K0 < n; K0 += NB, ++step) {
+    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
+      double* inv_j = inv + (j / BGP_IB) * (BGP_IB * BGP_IB);
+      int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)j, 64);
+      if (rc) return rc;
+      const int64_t rows_below = n - (j + BGP_IB);
+      if (rows_below > 0) {
+        double* A21 = A + (j + BGP_IB) + j * lda;
+        rc = launch_gemm_nt(h, st, 1, 64, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0);
+        if (rc) return rc;
+        const int64_t ncols = K0 + nbk - (j + BGP_IB);
+        if (ncols > 0) {
+          rc = launch_gemm_nt(h, st, 0, 128, A + (j + BGP_IB) + (j + BGP_IB) * lda, lda, A21, lda, A21, lda,
+                              rows_below, ncols, BGP_IB, 1);
+          if (rc) return rc;
+        }
+      }
+    }
+    const int64_t rows_trail = n - (K0 + nbk);
+    if (rows_trail > 0) {
+      double* P = A + (K0 + nbk) + K0 * lda;
+      if (time_trailing) {
+        if (h->ev_pool.size() < ev_used + 2) {
+          hipEvent_t e0, e1;
+          BGP_HIP(h, hipEventCreate(&e0));
+          BGP_HIP(h, hipEventCreate(&e1));
+          h->ev_pool.push_back(e0);
+          h->ev_pool.push_back(e1);
+        }
+        BGP_HIP(h, hipEventRecord(h->ev_pool[ev_used], st));
+      }
+      int rc = launch_gemm_nt(h, st, 0, 128, A + (K0 + nbk) + (K0 + nbk) * lda, lda, P, lda, P, lda,
+                              rows_trail, rows_trail, nbk, 1);
+      if (rc) return rc;
+      if (time_trailing) {
+        BGP_HIP(h, hipEventRecord(h->ev_pool[ev_used + 1], st));
+        ev_used += 2;
+      }
+      trail_flop += (double)rows_trail * (double)(rows_trail + 1) * (double)nbk;
+    }
+    // early exit on a failed pivot: look at the flag every 8 outer steps
+    if ((step & 7) == 7) {
+      BGP_HIP(h, hipMemcpyAsync(h->hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, st));
+      BGP_HIP(h, hipStreamSynchronize(st));
+      if (*h->hinfo != 0) break;
+    }
+  }
+  BGP_HIP(h, hipMemcpyAsync(h->hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, st));
+  BGP_HIP(h, hipStreamSynchronize(st));
+  *info_out = *h->hinfo;
+  if (time_trailing) {
+    double tot = 0.0;
+    for (size_t e = 0; e + 1 < ev_used; e += 2) {
+      float ms = 0.f;
+      BGP_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[e], h->ev_pool[e + 1]));
+      tot += ms;
+    }
+    h->times[BGP_T_TRAIL] = tot;
+    h->times[BGP_T_TRAIL_FLOP] = trail_flop;
+  }
+  return 0;
+}
+
+// ---- E <- E L^-T for a row block E[me, n] (column-major, rows contiguous) --------------------
+// Same two-level blocking as the factorisation: the rows of E are "extra rows below the
+// matrix".  Used for z^T = (L^-1 y)^T (me = 16, row 0) and V^T = (L^-1 K_X*)^T.
+int epass_driver(bgp_handle* h, hipStream_t st, double* E, int64_t lde, int64_t me, const double* A,
+                 int64_t n, int64_t lda, const double* inv) {
+  const int64_t NB = h->nb_outer;
+  for (int64_t K0 = 0; K0 < n; K0 += NB) {
+    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
+      const double* inv_j = inv + (j / BGP_IB) * (BGP_IB * BGP_IB);
+      double* Ej = E + j * lde;
+      int rc = launch_gemm_nt(h, st, 1, 64, Ej, lde, Ej, lde, inv_j, BGP_IB, me, BGP_IB, BGP_IB, 0);
+      if (rc) return rc;
+      const int64_t ncols = K0 + nbk - (j + BGP_IB);
+      if (ncols > 0) {
+        rc = launch_gemm_nt(h, st, 0, ncols >= 128 ? 128 : 64, E + (j + BGP_IB) * lde, lde, Ej, lde,
+                            A + (j + BGP_IB) + j * lda, lda, me, ncols, BGP_IB, 0);
+        if (rc) return rc;
+      }
+    }
+    const int64_t rows_trail = n - (K0 + nbk);
+    if (rows_trail > 0) {
+      int rc = launch_gemm_nt(h, st, 0, 128, E + (K0 + nbk) * lde, lde, E + K0 * lde, lde,
+                              A + (K0 + nbk) + K0 * lda, lda, me, rows_trail, nbk, 0);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+int ensure_part(bgp_handle* h, int64_t need) {
+  if (need <= h->part_cap) return 0;
+  dev_free(h, &h->dpart, h->part_cap);
+  h->part_cap = 0;
+  int rc = dev_alloc(h, &h->dpart, need);
+  if (rc) return rc;
+  h->part_cap = need;
+  return 0;
+}
+
+// alpha = L^-T z  (z = row 0 of the dz block, stride 16)
+int backward_driver(bgp_handle* h, hipStream_t st) {
+  const int64_t n = h->Npad, lda = h->lda;
+  int rc = ensure_part(h, ((n + 4095) / 4096 + 1) * 64);
+  if (rc) return rc;
+  for (int64_t j = n - BGP_IB; j >= 0; j -= BGP_IB) {
+    const int64_t rows = n - (j + BGP_IB);
+    int nch = 0;
+    if (rows > 0) {
+      rc = launch_gemvt_partial(h, st, h->dA + (j + BGP_IB) + j * lda, lda, h->dalpha + (j + BGP_IB), rows,
+                                h->dpart, &nch);
+      if (rc) return rc;
+    }
+    rc = launch_solve_tile_t(h, st, h->dInv + (j / BGP_IB) * (BGP_IB * BGP_IB), h->dz + j * 16, 16, h->dpart,
+                             nch, h->dalpha + j);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+void free_problem(bgp_handle* h) {
+  dev_free(h, &h->dA, h->lda * h->Npad);
+  dev_free(h, &h->dInv, h->Npad * BGP_IB);
+  dev_free(h, &h->dz, h->Npad * 16);
+  dev_free(h, &h->dalpha, h->Npad);
+  dev_free(h, &h->dX, h->N * h->D);
+  dev_free(h, &h->dy, h->N);
+  dev_free(h, &h->dE, h->E_rows_cap * h->Npad);
+  h->E_rows_cap = 0;
+  h->N = h->Npad = h->lda = 0;
+  h->D = 0;
+  h->fitted = false;
+}
+
+int alloc_problem(bgp_handle* h, int64_t N, int D) {
+  if (h->N == N && h->D == D && h->dA) return 0;
+  free_problem(h);
+  const int64_t Npad = round_up(N, BGP_IB);
+  // column stride: avoid large power-of-two strides (all columns of a tile in one HBM channel)
+  int64_t lda = Npad;
+  if (Npad >= 2048 && (Npad % 512) == 0) lda += 64;
+  h->N = N;
+  h->D = D;
+  h->Npad = Npad;
+  h->lda = lda;
+  int rc;
+  if ((rc = dev_alloc(h, &h->dX, N * D))) return rc;
+  if ((rc = dev_alloc(h, &h->dy, N))) return rc;
+  if ((rc = dev_alloc(h, &h->dInv, Npad * BGP_IB))) return rc;
+  if ((rc = dev_alloc(h, &h->dz, Npad * 16))) return rc;
+  if ((rc = dev_alloc(h, &h->dalpha, Npad))) return rc;
+  if ((rc = dev_alloc(h, &h->dA, lda * Npad))) {
+    free_problem(h);
+    return rc;
+  }
+  return 0;
+}
+
+// fill + jittered Cholesky + solves + lml on the resident X, y
+int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out) {
+  hipStream_t st = h->s_main;
+  const int64_t N = h->N, Npad = h->Npad, lda = h->lda;
+  h->fitted = false;
+  h->times[BGP_T_FILL] = h->times[BGP_T_POTRF] = 0.0;
+  double jitter = 0.0;
+  int info = 0;
+  for (int attempt = 0; attempt <= h->max_tries; ++attempt) {
+    FillParams p;
+    int rc = make_fill_params(h, h->D, jitter, &p);
+    if (rc) return rc;
+    {
+      PhaseTimer t(h, st, BGP_T_FILL, true);
+      rc = launch_fill(h, st, p, h->dX, Npad, h->dX, Npad, h->dA, lda, 1, 1, N, N);
+      if (rc) return rc;
+      if ((rc = t.stop())) return rc;
+    }
+    {
+      PhaseTimer t(h, st, BGP_T_POTRF, true);
+      rc = potrf_driver(h, st, h->dA, Npad, lda, h->dInv, h->dinfo, &info, true);
+      if (rc) return rc;
+      if ((rc = t.stop())) return rc;
+    }
+    if (info == 0) break;
+    if (attempt == h->max_tries) break;
+    jitter = h->jitter0 * pow(10.0, (double)attempt);
+  }
+  h->times[BGP_T_FILL_BYTES] = 4.0 * (double)N * (double)(N + 1);
+  if (info != 0) {
+    bgp_fail(h, info, "matrix not positive definite (leading minor %d) after jitter up to %.1e", info, jitter);
+    return info > 0 ? info : -4;
+  }
+  h->jitter_used = jitter;
+  {
+    PhaseTimer t(h, st, BGP_T_SOLVE);
+    int rc;
+    BGP_HIP(h, hipMemsetAsync(h->dz, 0, (size_t)Npad * 16 * sizeof(double), st));
+    if ((rc = launch_copy_strided(h, st, h->dy, N, h->dz, 16, Npad))) return rc;
+    if ((rc = epass_driver(h, st, h->dz, 16, 16, h->dA, Npad, lda, h->dInv))) return rc;
+    if ((rc = backward_driver(h, st))) return rc;
+    if ((rc = launch_fit_scalars(h, st, h->dA, lda, h->dz, 16, Npad, h->dscal))) return rc;
+    BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if ((rc = t.stop())) return rc;
+  }
+  const double logdet_half = h->hscal[0], zz = h->hscal[1];
+  h->lml = -0.5 * zz - logdet_half - 0.5 * (double)N * log(2.0 * M_PI);
+  h->fitted = true;
+  if (lml_out) *lml_out = h->lml;
+  if (jitter_out) *jitter_out = h->jitter_used;
+  return 0;
+}
+
+int ensure_query(bgp_handle* h, int64_t M) {
+  const int64_t Mpad = round_up(M, 16);
+  if (Mpad > h->E_rows_cap) {
+    dev_free(h, &h->dE, h->E_rows_cap * h->Npad);
+    h->E_rows_cap = 0;
+    int rc = dev_alloc(h, &h->dE, Mpad * h->Npad);
+    if (rc) return rc;
+    h->E_rows_cap = Mpad;
+  }
+  if (M * h->D > h->Xq_cap) {
+    dev_free(h, &h->dXq, h->Xq_cap);
+    h->Xq_cap = 0;
+    int rc = dev_alloc(h, &h->dXq, M * h->D);
+    if (rc) return rc;
+    h->Xq_cap = M * h->D;
+  }
+  if (2 * M > h->out_cap) {
+    dev_free(h, &h->dout, h->out_cap);
+    h->out_cap = 0;
+    int rc = dev_alloc(h, &h->dout, 2 * M);
+    if (rc) return rc;
+    h->out_cap = 2 * M;
+  }
+  return ensure_part(h, ((h->Npad + 511) / 512 + 1) * M);
+}
+
+// dXq holds the queries; results land in dout[0..M) (mean) and dout[M..2M) (var)
+int predict_resident(bgp_handle* h, int64_t M, bool want_var, double min_var) {
+  hipStream_t st = h->s_main;
+  const int64_t Mpad = round_up(M, 16), lde = Mpad, Npad = h->Npad;
+  FillParams p;
+  int rc = make_fill_params(h, h->D, 0.0, &p);
+  if (rc) return rc;
+  {
+    PhaseTimer t(h, st, BGP_T_CROSS);
+    if ((rc = launch_fill(h, st, p, h->dXq, Mpad, h->dX, Npad, h->dE, lde, 0, 0, M, h->N))) return rc;
+    int nch = 0;
+    if ((rc = launch_rowdot(h, st, h->dE, lde, M, Npad, h->dalpha, h->dpart, &nch))) return rc;
+    if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, nullptr, &p, -1.0, h->dout))) return rc;
+    if ((rc = t.stop())) return rc;
+  }
+  h->times[BGP_T_VAR] = 0.0;
+  if (want_var) {
+    PhaseTimer t(h, st, BGP_T_VAR);
+    if ((rc = epass_driver(h, st, h->dE, lde, Mpad, h->dA, Npad, h->lda, h->dInv))) return rc;
+    int nch = 0;
+    if ((rc = launch_rowdot(h, st, h->dE, lde, M, Npad, nullptr, h->dpart, &nch))) return rc;
+    if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, h->dXq, &p, min_var, h->dout + M))) return rc;
+    if ((rc = t.stop())) return rc;
+  }
+  return 0;
+}
+
+int check_handle(bgp_handle* h) {
+  if (!h) return -1;
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) return bgp_fail(h, -2, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bgp_version(void) { return 100; }
+
+int bgp_create(bgp_handle** out, int device) {
+  if (!out) return bgp_fail(nullptr, -1, "bgp_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    return bgp_fail(nullptr, -2, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  }
+  if (device < 0 || device >= ndev) return bgp_fail(nullptr, -1, "device %d out of range (0..%d)", device, ndev - 1);
+  bgp_handle* h = new bgp_handle();
+  h->device = device;
+#define CREATE_HIP(call)                                                                 \
+  do {                                                                                   \
+    hipError_t e2 = (call);                                                              \
+    if (e2 != hipSuccess) {                                                              \
+      bgp_fail(nullptr, -2, "%s failed: %s", #call, hipGetErrorString(e2));              \
+      bgp_destroy(h);                                                                    \
+      return -2;                                                                         \
+    }                                                                                    \
+  } while (0)
+  CREATE_HIP(hipSetDevice(device));
+  CREATE_HIP(hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking));
+  CREATE_HIP(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
+  CREATE_HIP(hipEventCreate(&h->ev_a));
+  CREATE_HIP(hipEventCreate(&h->ev_b));
+  CREATE_HIP(hipEventCreate(&h->ev_c));
+  CREATE_HIP(hipEventCreate(&h->ev_d));
+  CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&h->dscal), 16 * sizeof(double)));
+  CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&h->dinfo), 4 * sizeof(int)));
+  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->hscal), 16 * sizeof(double), hipHostMallocDefault));
+  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->hinfo), 4 * sizeof(int), hipHostMallocDefault));
+#undef CREATE_HIP
+  *out = h;
+  return 0;
+}
+
+void bgp_destroy(bgp_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->s_main) (void)hipStreamSynchronize(h->s_main);
+  free_problem(h);
+  dev_free(h, &h->dXq, h->Xq_cap);
+  dev_free(h, &h->dpart, h->part_cap);
+  dev_free(h, &h->dout, h->out_cap);
+  if (h->dscal) (void)hipFree(h->dscal);
+  if (h->dinfo) (void)hipFree(h->dinfo);
+  if (h->hscal) (void)hipHostFree(h->hscal);
+  if (h->hinfo) (void)hipHostFree(h->hinfo);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+  if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+  if (h->ev_c) (void)hipEventDestroy(h->ev_c);
+  if (h->ev_d) (void)hipEventDestroy(h->ev_d);
+  if (h->s_main) (void)hipStreamDestroy(h->s_main);
+  if (h->s_aux) (void)hipStreamDestroy(h->s_aux);
+  delete h;
+}
+
+const char* bgp_last_error(const bgp_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp) {
+  if (!h) return -1;
+  if (kernel_id < 0 || kernel_id > BGP_KERNEL_ARD_RBF) return bgp_fail(h, -1, "unknown kernel id %d", kernel_id);
+  if (!hyp || nhyp < 3 || nhyp > BGP_MAX_HYP) return bgp_fail(h, -1, "bad hyper-parameter vector (n=%d)", nhyp);
+  for (int i = 0; i < nhyp; ++i) {
+    if (!(hyp[i] == hyp[i]) || hyp[i] < 0.0 || (i > 0 && hyp[i] == 0.0) || isinf(hyp[i]))
+      return bgp_fail(h, -1, "hyper-parameter %d = %g is not a positive finite number", i, hyp[i]);
+  }
+  h->kernel_id = kernel_id;
+  h->nhyp = nhyp;
+  memcpy(h->hyp, hyp, sizeof(double) * nhyp);
+  h->kernel_set = true;
+  h->fitted = false;
+  return 0;
+}
+
+int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead) {
+  if (!h) return -1;
+  if (nb_outer >= 0) {
+    if (nb_outer < 64 || (nb_outer % 64) != 0) return bgp_fail(h, -1, "nb_outer must be a positive multiple of 64");
+    h->nb_outer = nb_outer;
+  }
+  if (max_tries >= 0) h->max_tries = max_tries;
+  if (jitter0 >= 0.0) h->jitter0 = jitter0;
+  if (lookahead >= 0) h->lookahead = lookahead;
+  return 0;
+}
+
+static int fit_common(bgp_handle* h, const double* X, const double* y, int64_t N, int D, bool on_device,
+                      double* lml_out, double* jitter_out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!X || !y || N < 1) return bgp_fail(h, -1, "bgp_fit: bad arguments (N=%lld)", (long long)N);
+  FillParams p;
+  if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
+  if ((rc = alloc_problem(h, N, D))) return rc;
+  {
+    PhaseTimer t(h, h->s_main, BGP_T_H2D);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    BGP_HIP(h, hipMemcpyAsync(h->dX, X, (size_t)N * D * sizeof(double), kind, h->s_main));
+    BGP_HIP(h, hipMemcpyAsync(h->dy, y, (size_t)N * sizeof(double), kind, h->s_main));
+    if ((rc = t.stop())) return rc;
+  }
+  return fit_resident(h, lml_out, jitter_out);
+}
+
+int bgp_fit(bgp_handle* h, const double* X_host, const double* y_host, int64_t N, int D, double* lml_out,
+            double* jitter_out) {
+  return fit_common(h, X_host, y_host, N, D, false, lml_out, jitter_out);
+}
+
+int bgp_fit_dev(bgp_handle* h, const double* X_dev, const double* y_dev, int64_t N, int D, double* lml_out,
+                double* jitter_out) {
+  return fit_common(h, X_dev, y_dev, N, D, true, lml_out, jitter_out);
+}
+
+int bgp_refit(bgp_handle* h, const double* hyp, int nhyp, double* lml_out, double* jitter_out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->dA || h->N < 1) return bgp_fail(h, -1, "bgp_refit: no resident problem (call bgp_fit first)");
+  if ((rc = bgp_set_kernel(h, h->kernel_id, hyp, nhyp))) return rc;
+  return fit_resident(h, lml_out, jitter_out);
+}
+
+static int predict_common(bgp_handle* h, const double* Xq, int64_t M, double* mean, double* var,
+                          double min_var, bool on_device) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->fitted) return bgp_fail(h, -1, "bgp_predict: no successful fit on this handle");
+  if (!Xq || M < 1 || !mean) return bgp_fail(h, -1, "bgp_predict: bad arguments (M=%lld)", (long long)M);
+  if ((rc = ensure_query(h, M))) return rc;
+  hipStream_t st = h->s_main;
+  const hipMemcpyKind kin = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const hipMemcpyKind kout = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  BGP_HIP(h, hipMemcpyAsync(h->dXq, Xq, (size_t)M * h->D * sizeof(double), kin, st));
+  if ((rc = predict_resident(h, M, var != nullptr, min_var))) return rc;
+  {
+    PhaseTimer t(h, st, BGP_T_D2H);
+    BGP_HIP(h, hipMemcpyAsync(mean, h->dout, (size_t)M * sizeof(double), kout, st));
+    if (var) BGP_HIP(h, hipMemcpyAsync(var, h->dout + M, (size_t)M * sizeof(double), kout, st));
+    if ((rc = t.stop())) return rc;
+  }
+  return 0;
+}
+
+int bgp_predict(bgp_handle* h, const double* Xq_host, int64_t M, double* mean_out, double* var_out,
+                double min_var) {
+  return predict_common(h, Xq_host, M, mean_out, var_out, min_var, false);
+}
+
+int bgp_predict_dev(bgp_handle* h, const double* Xq_dev, int64_t M, double* mean_dev, double* var_dev,
+                    double min_var) {
+  return predict_common(h, Xq_dev, M, mean_dev, var_dev, min_var, true);
+}
+
+int bgp_predict_cov(bgp_handle* h, const double* Xq_host, int64_t M, double* mean_out, double* cov_out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->fitted) return bgp_fail(h, -1, "bgp_predict_cov: no successful fit on this handle");
+  if (!Xq_host || M < 1 || !mean_out || !cov_out) return bgp_fail(h, -1, "bgp_predict_cov: bad arguments");
+  if ((rc = ensure_query(h, M))) return rc;
+  hipStream_t st = h->s_main;
+  const int64_t Mpad = round_up(M, 16);
+  BGP_HIP(h, hipMemcpyAsync(h->dXq, Xq_host, (size_t)M * h->D * sizeof(double), hipMemcpyHostToDevice, st));
+  // mean + V^T = E L^-T (variance vector is a by-product we do not need here)
+  if ((rc = predict_resident(h, M, true, -1.0))) return rc;
+  double* dC = nullptr;
+  if ((rc = dev_alloc(h, &dC, Mpad * Mpad))) return rc;
+  FillParams p;
+  rc = make_fill_params(h, h->D, 0.0, &p);
+  if (!rc) rc = launch_fill(h, st, p, h->dXq, Mpad, h->dXq, Mpad, dC, Mpad, 0, 0, M, M);
+  if (!rc) rc = launch_gemm_nt(h, st, 0, 128, dC, Mpad, h->dE, Mpad, h->dE, Mpad, Mpad, Mpad, h->Npad, 0);
+  if (!rc) {
+    hipError_t e = hipMemcpy2DAsync(cov_out, (size_t)M * sizeof(double), dC, (size_t)Mpad * sizeof(double),
+                                    (size_t)M * sizeof(double), (size_t)M, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(mean_out, h->dout, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = bgp_fail(h, -2, "predict_cov copy-out: %s", hipGetErrorString(e));
+  }
+  dev_free(h, &dC, Mpad * Mpad);
+  return rc;
+}
+
+int bgp_kernel_matrix(bgp_handle* h, const double* X1_host, int64_t n1, const double* X2_host, int64_t n2,
+                      int D, double* out_host) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!X1_host || n1 < 1 || !out_host) return bgp_fail(h, -1, "bgp_kernel_matrix: bad arguments");
+  if (!X2_host) {
+    X2_host = X1_host;
+    n2 = n1;
+  }
+  FillParams p;
+  if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
+  hipStream_t st = h->s_main;
+  double *d1 = nullptr, *d2 = nullptr, *dK = nullptr;
+  if ((rc = dev_alloc(h, &d1, n1 * D))) return rc;
+  if (!(rc = dev_alloc(h, &d2, n2 * D)) && !(rc = dev_alloc(h, &dK, n1 * n2))) {
+    hipError_t e = hipMemcpyAsync(d1, X1_host, (size_t)n1 * D * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2, X2_host, (size_t)n2 * D * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) rc = bgp_fail(h, -2, "kernel_matrix upload: %s", hipGetErrorString(e));
+    // row-major [n1, n2] == column-major [n2, n1] with ld = n2: rows of the fill are X2 points
+    if (!rc) rc = launch_fill(h, st, p, d2, n2, d1, n1, dK, n2, 0, 0, n2, n1);
+    if (!rc) {
+      e = hipMemcpyAsync(out_host, dK, (size_t)n1 * n2 * sizeof(double), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) rc = bgp_fail(h, -2, "kernel_matrix download: %s", hipGetErrorString(e));
+    }
+  }
+  dev_free(h, &d1, n1 * D);
+  dev_free(h, &d2, n2 * D);
+  dev_free(h, &dK, n1 * n2);
+  return rc;
+}
+
+int bgp_get_alpha(bgp_handle* h, double* alpha_host) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->fitted || !alpha_host) return bgp_fail(h, -1, "bgp_get_alpha: no fit / NULL output");
+  BGP_HIP(h, hipMemcpyAsync(alpha_host, h->dalpha, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->s_main));
+  BGP_HIP(h, hipStreamSynchronize(h->s_main));
+  return 0;
+}
+
+int bgp_residuals(bgp_handle* h, int nsample, double* out2) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->fitted || !out2) return bgp_fail(h, -1, "bgp_residuals: no fit / NULL output");
+  if (nsample < 2) nsample = 2;
+  if (nsample > 65536) nsample = 65536;
+  hipStream_t st = h->s_main;
+  FillParams p;
+  if ((rc = make_fill_params(h, h->D, 0.0, &p))) return rc;
+  const double diag_add = h->hyp[0] + h->jitter_used;
+  const int64_t need = h->N + nsample;
+  if ((rc = ensure_part(h, need))) return rc;
+  double* dr = h->dpart;
+  double* derr = h->dpart + h->N;
+  if ((rc = launch_kmatvec(h, st, p, h->dX, h->N, h->dalpha, diag_add, dr))) return rc;
+  if ((rc = launch_norm2(h, st, dr, h->dy, h->N, h->dscal + 2))) return rc;
+  if ((rc = launch_norm2(h, st, h->dy, nullptr, h->N, h->dscal + 3))) return rc;
+  if ((rc = launch_llt_sample(h, st, p, h->dX, h->dA, h->lda, h->N, diag_add, nsample, derr))) return rc;
+  std::vector<double> herr((size_t)nsample);
+  BGP_HIP(h, hipMemcpyAsync(h->hscal + 2, h->dscal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  BGP_HIP(h, hipMemcpyAsync(herr.data(), derr, (size_t)nsample * sizeof(double), hipMemcpyDeviceToHost, st));
+  BGP_HIP(h, hipStreamSynchronize(st));
+  out2[0] = sqrt(h->hscal[2]) / sqrt(h->hscal[3]);
+  double mx = 0.0;
+  for (double v : herr) mx = (v > mx || v != v) ? v : mx;
+  out2[1] = mx;
+  return 0;
+}
+
+int bgp_phase_times(const bgp_handle* h, double* out, int n) {
+  if (!h || !out) return -1;
+  for (int i = 0; i < n && i < BGP_T_COUNT; ++i) out[i] = h->times[i];
+  return 0;
+}
+
+int64_t bgp_device_bytes(const bgp_handle* h) { return h ? h->bytes : 0; }
+
+int bgp_potrf_dev(bgp_handle* h, double* A_dev, int64_t n, int64_t lda, int* info_out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!A_dev || n < 64 || (n % 64) != 0 || lda < n || (lda & 1))
+    return bgp_fail(h, -1, "bgp_potrf_dev: n must be a positive multiple of 64, lda even and >= n");
+  double* inv = nullptr;
+  if ((rc = dev_alloc(h, &inv, n * BGP_IB))) return rc;
+  int info = 0;
+  {
+    PhaseTimer t(h, h->s_main, BGP_T_POTRF);
+    rc = potrf_driver(h, h->s_main, A_dev, n, lda, inv, h->dinfo, &info, true);
+    if (!rc) rc = t.stop();
+  }
+  dev_free(h, &inv, n * BGP_IB);
+  if (info_out) *info_out = info;
+  return rc;
+}
+
+int bgp_gemm_nt_sub_dev(bgp_handle* h, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                        const double* B_dev, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  rc = launch_gemm_nt(h, h->s_main, 0, 128, C_dev, ldc, A_dev, lda, B_dev, ldb, m, n, k, lower);
+  if (rc) return rc;
+  BGP_HIP(h, hipStreamSynchronize(h->s_main));
+  return 0;
+}
+
+int bgp_fill_dev(bgp_handle* h, const double* x1_dev, int64_t n1, const double* x2_dev, int64_t n2, int D,
+                 double* out_dev, int64_t ld, int lower, double diag_add) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  FillParams p;
+  if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
+  const int add = (x1_dev == x2_dev && diag_add != 0.0) ? 1 : 0;
+  p.noise = diag_add;
+  {
+    PhaseTimer t(h, h->s_main, BGP_T_FILL);
+    rc = launch_fill(h, h->s_main, p, x1_dev, n1, x2_dev, n2, out_dev, ld, lower, add, n1, n2);
+    if (!rc) rc = t.stop();
+  }
+  h->times[BGP_T_FILL_BYTES] = lower ? 4.0 * (double)n1 * (double)(n1 + 1) : 8.0 * (double)n1 * (double)n2;
+  return rc;
+}
+
+}  // extern "C"

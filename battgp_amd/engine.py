@@ -1,0 +1,226 @@
+"""ExactGPEngine - thin Python owner of one ``bgp_handle`` (one GP on one MI355X).
+
+numpy in / numpy out, like the reference's ``IBatteryCellGP`` surface
+(``src/batt_models/batt_cell_gp_protocol.py:9-86``).  All arithmetic happens in
+libbattgp.so; this file only marshals pointers and maps return codes to the
+exceptions/warnings GPyTorch raises for the same conditions.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import dptr
+
+
+class EngineError(RuntimeError):
+    """HIP / allocation / argument error reported by libbattgp.so."""
+
+
+class NotPSDError(RuntimeError):
+    """Counterpart of ``linear_operator.utils.errors.NotPSDError`` (jitter ladder exhausted)."""
+
+
+class NumericalWarning(RuntimeWarning):
+    """Counterpart of ``linear_operator.utils.warnings.NumericalWarning`` (jitter was added);
+    the reference silences it at ``gp_runner.py:28``."""
+
+
+def as_device_index(device) -> int:
+    """Accept what the reference passes as ``device=``: int (``gp_runner.py:162-171``),
+    ``torch.device``, or a string like ``"cuda:1"``.  CPU devices are rejected: this engine
+    has no CPU path."""
+    if device is None:
+        return 0
+    if isinstance(device, (int, np.integer)):
+        return int(device)
+    s = str(device)
+    if s.startswith("cpu"):
+        raise EngineError(
+            "battgp_amd runs on MI355X only; pass device=<gpu index> or torch.device('cuda:N')"
+        )
+    if ":" in s:
+        return int(s.split(":")[1])
+    return 0
+
+
+class ExactGPEngine:
+    def __init__(self, kernel_id: int, hyp, device=0):
+        self._lib = _lib.load()
+        self._h = _lib.handle_p()
+        self.device_index = as_device_index(device)
+        rc = self._lib.bgp_create(C.byref(self._h), self.device_index)
+        if rc != 0:
+            msg = self._lib.bgp_last_error(None).decode()
+            self._h = None
+            raise EngineError(f"bgp_create failed ({rc}): {msg}")
+        self.kernel_id = int(kernel_id)
+        self.n = 0
+        self.d = 0
+        self.lml = None
+        self.jitter = None
+        self.set_hyp(hyp)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.bgp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc == 0:
+            return
+        msg = self._lib.bgp_last_error(self._h).decode()
+        if rc > 0:
+            raise NotPSDError(f"{what}: {msg}")
+        raise EngineError(f"{what} failed ({rc}): {msg}")
+
+    # -- configuration ------------------------------------------------------------------------
+    def set_hyp(self, hyp) -> None:
+        hyp = np.ascontiguousarray(np.asarray(hyp, dtype=np.float64).reshape(-1))
+        self.hyp = hyp.copy()
+        self._check(self._lib.bgp_set_kernel(self._h, self.kernel_id, dptr(hyp), hyp.size), "bgp_set_kernel")
+
+    def set_options(self, nb_outer=-1, max_tries=-1, jitter0=-1.0, lookahead=-1) -> None:
+        self._check(self._lib.bgp_set_options(self._h, nb_outer, max_tries, jitter0, lookahead), "bgp_set_options")
+
+    # -- fit / predict ------------------------------------------------------------------------
+    def _after_fit(self, lml, jit):
+        self.lml = float(lml.value)
+        self.jitter = float(jit.value)
+        if self.jitter > 0.0:
+            warnings.warn(f"A not p.d., added jitter of {self.jitter:.1e} to the diagonal", NumericalWarning)
+        return self.lml
+
+    def fit(self, x: np.ndarray, y: np.ndarray) -> float:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        if x.shape[0] != y.shape[0]:
+            raise ValueError("x and y disagree on N")
+        self.n, self.d = x.shape
+        lml, jit = C.c_double(), C.c_double()
+        rc = self._lib.bgp_fit(self._h, dptr(x), dptr(y), self.n, self.d, C.byref(lml), C.byref(jit))
+        self._check(rc, "bgp_fit")
+        return self._after_fit(lml, jit)
+
+    def fit_device(self, x_ptr: int, y_ptr: int, n: int, d: int) -> float:
+        """X[n,d], y[n] already resident on this engine's GPU (e.g. ``tensor.data_ptr()``)."""
+        self.n, self.d = int(n), int(d)
+        lml, jit = C.c_double(), C.c_double()
+        rc = self._lib.bgp_fit_dev(
+            self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), self.n, self.d, C.byref(lml), C.byref(jit)
+        )
+        self._check(rc, "bgp_fit_dev")
+        return self._after_fit(lml, jit)
+
+    def refit(self, hyp) -> float:
+        hyp = np.ascontiguousarray(np.asarray(hyp, dtype=np.float64).reshape(-1))
+        lml, jit = C.c_double(), C.c_double()
+        rc = self._lib.bgp_refit(self._h, dptr(hyp), hyp.size, C.byref(lml), C.byref(jit))
+        self._check(rc, "bgp_refit")
+        self.hyp = hyp.copy()
+        return self._after_fit(lml, jit)
+
+    def predict(self, xq: np.ndarray, want_var: bool = True, min_var: float = 1e-10):
+        xq = np.ascontiguousarray(xq, dtype=np.float64)
+        if xq.ndim == 1:
+            xq = xq.reshape(-1, self.d)
+        if xq.shape[1] != self.d:
+            raise ValueError(f"query has {xq.shape[1]} columns, model has {self.d}")
+        m = xq.shape[0]
+        mean = np.empty(m, dtype=np.float64)
+        var = np.empty(m, dtype=np.float64) if want_var else None
+        rc = self._lib.bgp_predict(
+            self._h, dptr(xq), m, dptr(mean), dptr(var) if want_var else None, float(min_var)
+        )
+        self._check(rc, "bgp_predict")
+        return (mean, var) if want_var else mean
+
+    def predict_device(self, xq_ptr: int, m: int, mean_ptr: int, var_ptr, min_var: float = 1e-10):
+        rc = self._lib.bgp_predict_dev(
+            self._h,
+            C.c_void_p(xq_ptr),
+            int(m),
+            C.c_void_p(mean_ptr),
+            C.c_void_p(var_ptr) if var_ptr else None,
+            float(min_var),
+        )
+        self._check(rc, "bgp_predict_dev")
+
+    def predict_cov(self, xq: np.ndarray):
+        xq = np.ascontiguousarray(xq, dtype=np.float64)
+        if xq.ndim == 1:
+            xq = xq.reshape(-1, self.d)
+        m = xq.shape[0]
+        mean = np.empty(m, dtype=np.float64)
+        cov = np.empty((m, m), dtype=np.float64)
+        self._check(self._lib.bgp_predict_cov(self._h, dptr(xq), m, dptr(mean), dptr(cov)), "bgp_predict_cov")
+        return mean, cov
+
+    def kernel_matrix(self, x1: np.ndarray, x2: np.ndarray | None = None) -> np.ndarray:
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        if x1.ndim == 1:
+            x1 = x1.reshape(-1, 1)
+        if x2 is None:
+            n2, p2 = x1.shape[0], None
+        else:
+            x2 = np.ascontiguousarray(x2, dtype=np.float64)
+            if x2.ndim == 1:
+                x2 = x2.reshape(-1, 1)
+            n2, p2 = x2.shape[0], dptr(x2)
+        out = np.empty((x1.shape[0], n2), dtype=np.float64)
+        rc = self._lib.bgp_kernel_matrix(self._h, dptr(x1), x1.shape[0], p2, n2, x1.shape[1], dptr(out))
+        self._check(rc, "bgp_kernel_matrix")
+        return out
+
+    def alpha(self) -> np.ndarray:
+        a = np.empty(self.n, dtype=np.float64)
+        self._check(self._lib.bgp_get_alpha(self._h, dptr(a)), "bgp_get_alpha")
+        return a
+
+    def residuals(self, nsample: int = 256):
+        out = np.zeros(2, dtype=np.float64)
+        self._check(self._lib.bgp_residuals(self._h, int(nsample), dptr(out)), "bgp_residuals")
+        return float(out[0]), float(out[1])
+
+    def phase_times(self) -> dict:
+        t = np.zeros(_lib.T_COUNT, dtype=np.float64)
+        self._lib.bgp_phase_times(self._h, dptr(t), _lib.T_COUNT)
+        names = [
+            "h2d_ms", "fill_ms", "potrf_ms", "solve_ms", "cross_ms", "var_ms", "d2h_ms",
+            "trail_ms", "trail_flop", "fill_bytes",
+        ]
+        return dict(zip(names, (float(v) for v in t)))
+
+    def device_bytes(self) -> int:
+        return int(self._lib.bgp_device_bytes(self._h))
+
+    # -- building blocks on raw device pointers (tests, bench roofline, sharded driver) ----------
+    def potrf_device(self, a_ptr: int, n: int, lda: int) -> int:
+        info = C.c_int(0)
+        self._check(self._lib.bgp_potrf_dev(self._h, C.c_void_p(a_ptr), n, lda, C.byref(info)), "bgp_potrf_dev")
+        return int(info.value)
+
+    def gemm_nt_sub_device(self, c_ptr, ldc, a_ptr, lda, b_ptr, ldb, m, n, k, lower=0) -> None:
+        rc = self._lib.bgp_gemm_nt_sub_dev(
+            self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda, C.c_void_p(b_ptr), ldb, m, n, k, int(lower)
+        )
+        self._check(rc, "bgp_gemm_nt_sub_dev")
+
+    def fill_device(self, x1_ptr, n1, x2_ptr, n2, d, out_ptr, ld, lower=0, diag_add=0.0) -> None:
+        rc = self._lib.bgp_fill_dev(
+            self._h, C.c_void_p(x1_ptr), n1, C.c_void_p(x2_ptr), n2, d, C.c_void_p(out_ptr), ld, int(lower), float(diag_add)
+        )
+        self._check(rc, "bgp_fill_dev")

@@ -1,0 +1,165 @@
+/*
+ * battgp.h - C-ABI of the MI355X-native exact-GP engine (libbattgp.so).
+ *
+ * This is the drop-in boundary for BattGP's `full_gp` hot path.  The reference is pure
+ * Python over gpytorch/torch (no FFI of its own), so every entry point below names the
+ * reference call site whose device work it replaces (paths relative to the reference
+ * root).  Plain pointers and sizes only; no torch types.  The reference-side binding (a
+ * ctypes stub) is shown in INTEGRATION.md and implemented in battgp_amd/_lib.py.
+ *
+ * Conventions
+ *   - all floating point data is IEEE fp64;
+ *   - X / Xq are row-major [N, D] / [M, D] exactly as IBatteryCellGP defines them
+ *     (src/batt_models/batt_cell_gp_protocol.py:18-30: time[days], I[A], SOC[%], T[degC]);
+ *   - *_host pointers are borrowed for the duration of the call, *_dev pointers are HIP
+ *     device pointers on the handle's device (e.g. torch.Tensor.data_ptr()) that must
+ *     already be complete on entry (the engine runs on its own streams);
+ *   - return value: 0 ok; > 0 = matrix not positive definite after the jitter ladder
+ *     (value = 1-based index of the failing leading minor); < 0 = argument / HIP /
+ *     allocation error, text available from bgp_last_error();
+ *   - a handle is single-threaded; distinct handles (also on distinct GPUs) are
+ *     independent and may be driven from different host threads concurrently
+ *     (src/batt_models/battgp.py:191-216 trains cells from a thread pool).
+ *
+ * Hyper-parameter vector layout (hyp):
+ *   BGP_KERNEL_BATTGP      [noise, s_wiener, s_rbf, l_1 .. l_{D-1}]   (src/batt_models/cell_gp.py:27-36,
+ *                           WienerKernel on column 0: src/gp/wiener_kernel.py:10-32)
+ *   BGP_KERNEL_SCALED_RBF  [noise, s, l]                               (src/gp/standard_models.py:24-28)
+ *   BGP_KERNEL_MATERN32    [noise, s, l_1 .. l_D]                      (BASELINE config 3; no reference call site)
+ *   BGP_KERNEL_ARD_RBF     [noise, s, l_1 .. l_D]                      (tests/gp/test_spatiotemporal_gp.py:65-81)
+ */
+#ifndef BATTGP_H
+#define BATTGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bgp_handle bgp_handle;
+
+enum {
+  BGP_KERNEL_BATTGP = 0,
+  BGP_KERNEL_SCALED_RBF = 1,
+  BGP_KERNEL_MATERN32 = 2,
+  BGP_KERNEL_ARD_RBF = 3
+};
+
+#define BGP_MAX_DIM 8
+#define BGP_MAX_HYP (BGP_MAX_DIM + 3)
+
+/* indices into the bgp_phase_times() array (milliseconds, last call of each phase) */
+enum {
+  BGP_T_H2D = 0,      /* host->device upload of X, y                    */
+  BGP_T_FILL = 1,     /* covariance fill  K + (noise+jitter) I           */
+  BGP_T_POTRF = 2,    /* blocked Cholesky (all attempts of the ladder)   */
+  BGP_T_SOLVE = 3,    /* z = L^-1 y, alpha = L^-T z, log det, y^T alpha  */
+  BGP_T_CROSS = 4,    /* cross-covariance fill + posterior mean          */
+  BGP_T_VAR = 5,      /* V = L^-1 K_X*, predictive variance              */
+  BGP_T_D2H = 6,      /* device->host of results                         */
+  BGP_T_TRAIL = 7,    /* sum of the outer trailing-update (MFMA SYRK) launches of the last potrf */
+  BGP_T_TRAIL_FLOP = 8, /* algorithmic flop of those launches (2*m*n*k per full tile pair, lower half) */
+  BGP_T_FILL_BYTES = 9, /* algorithmic bytes written by the last training fill */
+  BGP_T_COUNT = 10
+};
+
+/* Library version (major*10000 + minor*100 + patch). */
+int bgp_version(void);
+
+/* Create / destroy an engine bound to HIP device `device`.  The handle owns every device
+ * buffer (K/L in place, X, y, alpha, workspaces); bgp_destroy frees them - this is what
+ * `del cellmodel.model; gc.collect(); torch.cuda.empty_cache()` does in the reference
+ * (src/batt_models/battgp_full.py:102-120). */
+int bgp_create(bgp_handle** out, int device);
+void bgp_destroy(bgp_handle* h);
+
+/* Text of the last error on this handle ("" if none).  With h == NULL: last create error. */
+const char* bgp_last_error(const bgp_handle* h);
+
+/* Select the covariance function and its hyper-parameters.  Replaces the gpytorch module
+ * construction + property setters of src/batt_models/cell_gp.py:27-36,64-194 and
+ * src/batt_models/battcellgp_full.py:71-84.  Values are taken verbatim as fp64. */
+int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
+
+/* Tuning / numerical options.  Any argument < 0 (or NaN) keeps the current value.
+ *   nb_outer         outer panel width of the blocked Cholesky (multiple of 64; default 512)
+ *   max_tries        rungs of the jitter ladder after the plain attempt (default 3)
+ *   jitter0          first rung (default 1e-8: linear_operator psd_safe_cholesky, fp64)
+ *   lookahead        1 = overlap the next panel with the trailing update (default 1)     */
+int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
+
+/* FIT: upload (or adopt) X[N,D], y[N]; fill Sigma = K(X,X) + noise I in HBM; jittered
+ * blocked Cholesky in place; z = L^-1 y; alpha = Sigma^-1 y; log-marginal likelihood
+ *   lml = -1/2 y^T alpha - sum_i log L_ii - N/2 log 2 pi.
+ * Replaces: DefaultPredictionStrategy / mean_cache + ExactMarginalLogLikelihood as used at
+ * src/batt_models/battcellgp_full.py:171-173 and src/gp/training.py:27-30,39-41; jitter
+ * ladder = psd_safe_cholesky (evidence: gp_runner.py:14,28).  *jitter_out = jitter added
+ * (0 when the plain attempt succeeded). */
+int bgp_fit(bgp_handle* h, const double* X_host, const double* y_host, int64_t N, int D,
+            double* lml_out, double* jitter_out);
+int bgp_fit_dev(bgp_handle* h, const double* X_dev, const double* y_dev, int64_t N, int D,
+                double* lml_out, double* jitter_out);
+
+/* Re-fit with new hyper-parameters on the resident X, y (no re-upload): one LML evaluation
+ * of the optimiser loops in src/gp/training.py:39-41,126-145. */
+int bgp_refit(bgp_handle* h, const double* hyp, int nhyp, double* lml_out, double* jitter_out);
+
+/* PREDICT: posterior of the latent f at Xq[M,D] (no noise added):
+ *   mean = K_*X alpha;  var = diag(K_**) - colsumsq(L^-1 K_X*), floored at min_var
+ *   (pass min_var < 0 for the unclamped diagonal of src/gp/standard_models.py:48;
+ *    1e-10 mirrors MultivariateNormal.variance at battcellgp_full.py:180).
+ * var_out may be NULL (the `no_cov` path of battcellgp_full.py:177-178: mean only, no TRSM).
+ * Replaces ExactGP.__call__ (eval) at battcellgp_full.py:171-180, standard_models.py:40-48. */
+int bgp_predict(bgp_handle* h, const double* Xq_host, int64_t M, double* mean_out,
+                double* var_out, double min_var);
+int bgp_predict_dev(bgp_handle* h, const double* Xq_dev, int64_t M, double* mean_dev,
+                    double* var_dev, double min_var);
+
+/* Full posterior covariance [M, M] (row-major, symmetric) for
+ * ScaledRBFModel.predict(full_cov=True), src/gp/standard_models.py:45-46. */
+int bgp_predict_cov(bgp_handle* h, const double* Xq_host, int64_t M, double* mean_out,
+                    double* cov_out);
+
+/* Dense prior covariance K(X1, X2) -> out[n1, n2] row-major on the host, computed by the
+ * same fill kernel as the fit (no noise).  X2_host == NULL means X2 = X1.  Replaces
+ * kernel(x1, x2).to_dense() (WienerKernel.forward, src/gp/wiener_kernel.py:10-32). */
+int bgp_kernel_matrix(bgp_handle* h, const double* X1_host, int64_t n1, const double* X2_host,
+                      int64_t n2, int D, double* out_host);
+
+/* Copy alpha = Sigma^-1 y (length N) of the last fit to the host. */
+int bgp_get_alpha(bgp_handle* h, double* alpha_host);
+
+/* On-device residual checks of the last fit (for sizes the CPU oracle cannot reach):
+ *   out[0] = || Sigma alpha - y ||_2 / || y ||_2        (Sigma re-evaluated tile by tile)
+ *   out[1] = max over `nsample` sampled entries of |(L L^T)_ij - Sigma_ij| / Sigma_ii-scale */
+int bgp_residuals(bgp_handle* h, int nsample, double* out2);
+
+/* Per-phase timings of the most recent calls, see BGP_T_* (n <= BGP_T_COUNT values). */
+int bgp_phase_times(const bgp_handle* h, double* out, int n);
+
+/* Bytes of device memory currently owned by the handle. */
+int64_t bgp_device_bytes(const bgp_handle* h);
+
+/* ---- building blocks, exported for tests, the bench roofline and the sharded driver ---- */
+
+/* In-place lower Cholesky of a device matrix A[n, n] (column-major, leading dimension lda,
+ * lower triangle referenced).  info_out: 0 ok, k > 0 = leading minor k not positive.
+ * n and lda must be multiples of 64 is NOT required: any n >= 1, lda >= n. */
+int bgp_potrf_dev(bgp_handle* h, double* A_dev, int64_t n, int64_t lda, int* info_out);
+
+/* C[m, n] -= A[m, k] * B[n, k]^T on device, all column-major; lower != 0 restricts the update
+ * to tiles touching i >= j (SYRK-style trailing update).  k must be a multiple of 16. */
+int bgp_gemm_nt_sub_dev(bgp_handle* h, double* C_dev, int64_t ldc, const double* A_dev,
+                        int64_t lda, const double* B_dev, int64_t ldb, int64_t m, int64_t n,
+                        int64_t k, int lower);
+
+/* Fill out_dev[i + j*ld] = k(x1_i, x2_j) (+ diag_add on i == j when x2_dev == x1_dev) for the
+ * handle's kernel; lower != 0 writes only tiles on or below the diagonal. */
+int bgp_fill_dev(bgp_handle* h, const double* x1_dev, int64_t n1, const double* x2_dev,
+                 int64_t n2, int D, double* out_dev, int64_t ld, int lower, double diag_add);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BATTGP_H */
