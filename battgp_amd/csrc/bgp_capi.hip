@@ -116,76 +116,157 @@ struct PhaseTimer {
 //  outer panels of width NB: inside a panel, 64-wide steps {tile potrf+inverse, TRSM by the
 //  inverse (MFMA), rank-64 update of the rest of the panel (MFMA)}; then one rank-NB SYRK
 //  update of the whole trailing matrix (MFMA) - the kernel that carries ~all the flops.
+//
+//  Look-ahead (h->lookahead): the trailing update of panel k is split into the columns of
+//  panel k+1 ("la", on the panel stream sp) and the rest ("rest", on the main stream st), so
+//  that the latency-bound factorisation of panel k+1 runs on sp underneath rest(k):
+//      sp: panel(0) la(0) panel(1) [wait rest(0)] la(1) panel(2) [wait rest(1)] la(2) ...
+//      st:          [wait panel(0)] rest(0) [wait panel(1)] rest(1) ...
+//  Every element still receives exactly the same single rank-NB update, so the factor is
+//  bit-identical with and without look-ahead.
+int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t lda, double* inv, int* dinfo,
+                 int64_t K0, int64_t nbk) {
+  for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
+    double* inv_j = inv + (j / BGP_IB) * (BGP_IB * BGP_IB);
+    int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)j, 64);
+    if (rc) return rc;
+    const int64_t rows_below = n - (j + BGP_IB);
+    if (rows_below > 0) {
+      double* A21 = A + (j + BGP_IB) + j * lda;
+      rc = launch_gemm_nt(h, st, 1, 64, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0);
+      if (rc) return rc;
+      const int64_t ncols = K0 + nbk - (j + BGP_IB);
+      if (ncols > 0) {
+        rc = launch_gemm_nt(h, st, 0, 128, A + (j + BGP_IB) + (j + BGP_IB) * lda, lda, A21, lda, A21, lda,
+                            rows_below, ncols, BGP_IB, 1);
+        if (rc) return rc;
+      }
+    }
+  }
+  return 0;
+}
+
+struct TrailTimer {
+  bgp_handle* h;
+  bool on;
+  size_t used = 0;
+  double flop = 0.0;
+  int begin(hipStream_t st) {
+    if (!on) return 0;
+    while (h->ev_pool.size() < used + 2) {
+      hipEvent_t e;
+      BGP_HIP(h, hipEventCreate(&e));
+      h->ev_pool.push_back(e);
+    }
+    BGP_HIP(h, hipEventRecord(h->ev_pool[used], st));
+    return 0;
+  }
+  int end(hipStream_t st, double m, double ncols_full, double k, bool square) {
+    // algorithmic flop of a lower (trapezoid) rank-k update: 2 k * #entries(i >= j)
+    flop += square ? m * (m + 1.0) * k : 2.0 * k * (ncols_full * (m - ncols_full) + ncols_full * (ncols_full + 1.0) / 2.0);
+    if (!on) return 0;
+    BGP_HIP(h, hipEventRecord(h->ev_pool[used + 1], st));
+    used += 2;
+    return 0;
+  }
+  int finish() {
+    double tot = 0.0;
+    if (on) {
+      for (size_t e = 0; e + 1 < used; e += 2) {
+        float ms = 0.f;
+        BGP_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[e], h->ev_pool[e + 1]));
+        tot += ms;
+      }
+      h->times[BGP_T_TRAIL] = tot;
+      h->times[BGP_T_TRAIL_FLOP] = flop;
+    }
+    return 0;
+  }
+};
+
+int sync_event(bgp_handle* h, size_t idx, hipEvent_t* out) {
+  while (h->ev_sync.size() <= idx) {
+    hipEvent_t e;
+    BGP_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->ev_sync.push_back(e);
+  }
+  *out = h->ev_sync[idx];
+  return 0;
+}
+
+int check_info(bgp_handle* h, hipStream_t st, hipStream_t sp, int* dinfo, int* out) {
+  if (sp) BGP_HIP(h, hipStreamSynchronize(sp));
+  BGP_HIP(h, hipMemcpyAsync(h->hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, st));
+  BGP_HIP(h, hipStreamSynchronize(st));
+  *out = *h->hinfo;
+  return 0;
+}
+
 int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t lda, double* inv, int* dinfo,
                  int* info_out, bool time_trailing) {
   const int64_t NB = h->nb_outer;
+  const bool la = h->lookahead != 0 && n > 2 * NB;
+  hipStream_t sp = la ? h->s_aux : st;
   BGP_HIP(h, hipMemsetAsync(dinfo, 0, sizeof(int), st));
-  size_t ev_used = 0;
-  double trail_flop = 0.0;
-  int step = 0;
+  TrailTimer tt{h, time_trailing};
   *info_out = 0;
+  int rc;
+  hipEvent_t ev;
+  if (la) {  // sp must not start before the caller's work on st (fill, memset) is complete
+    if ((rc = sync_event(h, 0, &ev))) return rc;
+    BGP_HIP(h, hipEventRecord(ev, st));
+    BGP_HIP(h, hipStreamWaitEvent(sp, ev, 0));
+  }
+  int step = 0;
   for (int64_t K0 = 0; K0 < n; K0 += NB, ++step) {
     const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
-    for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
-      double* inv_j = inv + (j / BGP_IB) * (BGP_IB * BGP_IB);
-      int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)j, 64);
-      if (rc) return rc;
-      const int64_t rows_below = n - (j + BGP_IB);
-      if (rows_below > 0) {
-        double* A21 = A + (j + BGP_IB) + j * lda;
-        rc = launch_gemm_nt(h, st, 1, 64, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0);
-        if (rc) return rc;
-        const int64_t ncols = K0 + nbk - (j + BGP_IB);
-        if (ncols > 0) {
-          rc = launch_gemm_nt(h, st, 0, 128, A + (j + BGP_IB) + (j + BGP_IB) * lda, lda, A21, lda, A21, lda,
-                              rows_below, ncols, BGP_IB, 1);
-          if (rc) return rc;
-        }
-      }
-    }
-    const int64_t rows_trail = n - (K0 + nbk);
+    const int64_t K1 = K0 + nbk;
+    const int64_t rows_trail = n - K1;
+    if ((rc = factor_panel(h, sp, A, n, lda, inv, dinfo, K0, nbk))) return rc;
     if (rows_trail > 0) {
-      double* P = A + (K0 + nbk) + K0 * lda;
-      if (time_trailing) {
-        if (h->ev_pool.size() < ev_used + 2) {
-          hipEvent_t e0, e1;
-          BGP_HIP(h, hipEventCreate(&e0));
-          BGP_HIP(h, hipEventCreate(&e1));
-          h->ev_pool.push_back(e0);
-          h->ev_pool.push_back(e1);
+      double* P = A + K1 + K0 * lda;
+      if (!la) {
+        if ((rc = tt.begin(st))) return rc;
+        rc = launch_gemm_nt(h, st, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail, rows_trail, nbk, 1);
+        if (rc) return rc;
+        if ((rc = tt.end(st, (double)rows_trail, (double)rows_trail, (double)nbk, true))) return rc;
+      } else {
+        const int64_t nbn = (rows_trail < NB) ? rows_trail : NB;  // width of the next panel
+        const int64_t K2 = K1 + nbn;
+        // panel(k) complete -> rest(k) may start on st
+        if ((rc = sync_event(h, 1 + 2 * (size_t)step, &ev))) return rc;
+        BGP_HIP(h, hipEventRecord(ev, sp));
+        BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
+        // la(k) on sp rewrites columns that rest(k-1) also updated: order it after rest(k-1)
+        if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + 2 * (size_t)(step - 1)], 0));
+        if ((rc = tt.begin(sp))) return rc;
+        rc = launch_gemm_nt(h, sp, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail, nbn, nbk, 1);
+        if (rc) return rc;
+        if ((rc = tt.end(sp, (double)rows_trail, (double)nbn, (double)nbk, false))) return rc;
+        // rest(k) on st: everything right of the next panel
+        const int64_t rows_rest = n - K2;
+        if (rows_rest > 0) {
+          const double* P2 = A + K2 + K0 * lda;
+          if ((rc = tt.begin(st))) return rc;
+          rc = launch_gemm_nt(h, st, 0, 128, A + K2 + K2 * lda, lda, P2, lda, P2, lda, rows_rest, rows_rest, nbk, 1);
+          if (rc) return rc;
+          if ((rc = tt.end(st, (double)rows_rest, (double)rows_rest, (double)nbk, true))) return rc;
         }
-        BGP_HIP(h, hipEventRecord(h->ev_pool[ev_used], st));
+        if ((rc = sync_event(h, 2 + 2 * (size_t)step, &ev))) return rc;
+        BGP_HIP(h, hipEventRecord(ev, st));
       }
-      int rc = launch_gemm_nt(h, st, 0, 128, A + (K0 + nbk) + (K0 + nbk) * lda, lda, P, lda, P, lda,
-                              rows_trail, rows_trail, nbk, 1);
-      if (rc) return rc;
-      if (time_trailing) {
-        BGP_HIP(h, hipEventRecord(h->ev_pool[ev_used + 1], st));
-        ev_used += 2;
-      }
-      trail_flop += (double)rows_trail * (double)(rows_trail + 1) * (double)nbk;
     }
     // early exit on a failed pivot: look at the flag every 8 outer steps
     if ((step & 7) == 7) {
-      BGP_HIP(h, hipMemcpyAsync(h->hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, st));
-      BGP_HIP(h, hipStreamSynchronize(st));
-      if (*h->hinfo != 0) break;
+      int info = 0;
+      if ((rc = check_info(h, st, la ? sp : nullptr, dinfo, &info))) return rc;
+      if (info != 0) break;
     }
   }
-  BGP_HIP(h, hipMemcpyAsync(h->hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, st));
-  BGP_HIP(h, hipStreamSynchronize(st));
-  *info_out = *h->hinfo;
-  if (time_trailing) {
-    double tot = 0.0;
-    for (size_t e = 0; e + 1 < ev_used; e += 2) {
-      float ms = 0.f;
-      BGP_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[e], h->ev_pool[e + 1]));
-      tot += ms;
-    }
-    h->times[BGP_T_TRAIL] = tot;
-    h->times[BGP_T_TRAIL_FLOP] = trail_flop;
-  }
-  return 0;
+  int info = 0;
+  if ((rc = check_info(h, st, la ? sp : nullptr, dinfo, &info))) return rc;
+  *info_out = info;
+  return tt.finish();
 }
 
 // ---- E <- E L^-T for a row block E[me, n] (column-major, rows contiguous) --------------------
@@ -228,21 +309,40 @@ int ensure_part(bgp_handle* h, int64_t need) {
   return 0;
 }
 
-// alpha = L^-T z  (z = row 0 of the dz block, stride 16)
-int backward_driver(bgp_handle* h, hipStream_t st) {
-  const int64_t n = h->Npad, lda = h->lda;
-  int rc = ensure_part(h, ((n + 4095) / 4096 + 1) * 64);
-  if (rc) return rc;
-  for (int64_t j = n - BGP_IB; j >= 0; j -= BGP_IB) {
-    const int64_t rows = n - (j + BGP_IB);
-    int nch = 0;
-    if (rows > 0) {
-      rc = launch_gemvt_partial(h, st, h->dA + (j + BGP_IB) + j * lda, lda, h->dalpha + (j + BGP_IB), rows,
-                                h->dpart, &nch);
+// z = L^-1 y : dz holds y (zero padded) on entry and z on exit
+int forward_driver(bgp_handle* h, hipStream_t st) {
+  const int64_t n = h->Npad, lda = h->lda, NB = h->nb_outer;
+  for (int64_t K0 = 0; K0 < n; K0 += NB) {
+    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    const int64_t K1 = K0 + nbk;
+    int rc = launch_trsv_block_fwd(h, st, h->dA + K0 + K0 * lda, lda, h->dInv + (K0 / BGP_IB) * (BGP_IB * BGP_IB),
+                                   h->dz + K0, (int)nbk);
+    if (rc) return rc;
+    if (n - K1 > 0) {
+      rc = launch_gemv_n_sub(h, st, h->dA + K1 + K0 * lda, lda, h->dz + K0, (int)nbk, h->dz + K1, n - K1);
       if (rc) return rc;
     }
-    rc = launch_solve_tile_t(h, st, h->dInv + (j / BGP_IB) * (BGP_IB * BGP_IB), h->dz + j * 16, 16, h->dpart,
-                             nch, h->dalpha + j);
+  }
+  return 0;
+}
+
+// alpha = L^-T z
+int backward_driver(bgp_handle* h, hipStream_t st) {
+  const int64_t n = h->Npad, lda = h->lda, NB = h->nb_outer;
+  int rc = ensure_part(h, ((n + 1023) / 1024 + 1) * NB);
+  if (rc) return rc;
+  const int64_t nblk = (n + NB - 1) / NB;
+  for (int64_t b = nblk - 1; b >= 0; --b) {
+    const int64_t K0 = b * NB;
+    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    const int64_t K1 = K0 + nbk;
+    int nch = 0;
+    if (n - K1 > 0) {
+      rc = launch_gemv_t_partial(h, st, h->dA + K1 + K0 * lda, lda, h->dalpha + K1, n - K1, (int)nbk, h->dpart, &nch);
+      if (rc) return rc;
+    }
+    rc = launch_trsv_block_bwd(h, st, h->dA + K0 + K0 * lda, lda, h->dInv + (K0 / BGP_IB) * (BGP_IB * BGP_IB),
+                               h->dz + K0, h->dpart, nch, (int)nbk, h->dalpha + K0);
     if (rc) return rc;
   }
   return 0;
@@ -251,7 +351,7 @@ int backward_driver(bgp_handle* h, hipStream_t st) {
 void free_problem(bgp_handle* h) {
   dev_free(h, &h->dA, h->lda * h->Npad);
   dev_free(h, &h->dInv, h->Npad * BGP_IB);
-  dev_free(h, &h->dz, h->Npad * 16);
+  dev_free(h, &h->dz, h->Npad);
   dev_free(h, &h->dalpha, h->Npad);
   dev_free(h, &h->dX, h->N * h->D);
   dev_free(h, &h->dy, h->N);
@@ -277,7 +377,7 @@ int alloc_problem(bgp_handle* h, int64_t N, int D) {
   if ((rc = dev_alloc(h, &h->dX, N * D))) return rc;
   if ((rc = dev_alloc(h, &h->dy, N))) return rc;
   if ((rc = dev_alloc(h, &h->dInv, Npad * BGP_IB))) return rc;
-  if ((rc = dev_alloc(h, &h->dz, Npad * 16))) return rc;
+  if ((rc = dev_alloc(h, &h->dz, Npad))) return rc;
   if ((rc = dev_alloc(h, &h->dalpha, Npad))) return rc;
   if ((rc = dev_alloc(h, &h->dA, lda * Npad))) {
     free_problem(h);
@@ -323,11 +423,10 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out) {
   {
     PhaseTimer t(h, st, BGP_T_SOLVE);
     int rc;
-    BGP_HIP(h, hipMemsetAsync(h->dz, 0, (size_t)Npad * 16 * sizeof(double), st));
-    if ((rc = launch_copy_strided(h, st, h->dy, N, h->dz, 16, Npad))) return rc;
-    if ((rc = epass_driver(h, st, h->dz, 16, 16, h->dA, Npad, lda, h->dInv))) return rc;
+    if ((rc = launch_copy_strided(h, st, h->dy, N, h->dz, 1, Npad))) return rc;
+    if ((rc = forward_driver(h, st))) return rc;
     if ((rc = backward_driver(h, st))) return rc;
-    if ((rc = launch_fit_scalars(h, st, h->dA, lda, h->dz, 16, Npad, h->dscal))) return rc;
+    if ((rc = launch_fit_scalars(h, st, h->dA, lda, h->dz, 1, Npad, h->dscal))) return rc;
     BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     if ((rc = t.stop())) return rc;
   }
@@ -428,7 +527,11 @@ int bgp_create(bgp_handle** out, int device) {
   } while (0)
   CREATE_HIP(hipSetDevice(device));
   CREATE_HIP(hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking));
-  CREATE_HIP(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
+  {
+    int prio_lo = 0, prio_hi = 0;
+    CREATE_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    CREATE_HIP(hipStreamCreateWithPriority(&h->s_aux, hipStreamNonBlocking, prio_hi));
+  }
   CREATE_HIP(hipEventCreate(&h->ev_a));
   CREATE_HIP(hipEventCreate(&h->ev_b));
   CREATE_HIP(hipEventCreate(&h->ev_c));
@@ -455,6 +558,7 @@ void bgp_destroy(bgp_handle* h) {
   if (h->hscal) (void)hipHostFree(h->hscal);
   if (h->hinfo) (void)hipHostFree(h->hinfo);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
   if (h->ev_c) (void)hipEventDestroy(h->ev_c);
@@ -485,7 +589,8 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp) {
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead) {
   if (!h) return -1;
   if (nb_outer >= 0) {
-    if (nb_outer < 64 || (nb_outer % 64) != 0) return bgp_fail(h, -1, "nb_outer must be a positive multiple of 64");
+    if (nb_outer < 64 || (nb_outer % 64) != 0 || nb_outer > 2048)
+      return bgp_fail(h, -1, "nb_outer must be a multiple of 64 in [64, 2048]");
     h->nb_outer = nb_outer;
   }
   if (max_tries >= 0) h->max_tries = max_tries;

@@ -24,7 +24,8 @@ struct bgp_handle {
   int device = 0;
   hipStream_t s_main = nullptr, s_aux = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
-  std::vector<hipEvent_t> ev_pool;  // pairs around trailing updates
+  std::vector<hipEvent_t> ev_pool;  // timing pairs around trailing updates
+  std::vector<hipEvent_t> ev_sync;  // cross-stream dependencies of the look-ahead schedule
   // kernel
   bool kernel_set = false;
   int kernel_id = 0, nhyp = 0;
@@ -44,7 +45,7 @@ struct bgp_handle {
   double* dy = nullptr;      // [N]
   double* dA = nullptr;      // [lda, Npad] column-major, lower triangle = Sigma then L
   double* dInv = nullptr;    // [Npad/64][64*64] inverses of the diagonal tiles of L
-  double* dz = nullptr;      // [16, Npad] column-major row block whose row 0 is z^T = (L^-1 y)^T
+  double* dz = nullptr;      // [Npad] z = L^-1 y (zero in the padding)
   double* dalpha = nullptr;  // [Npad]
   double* dE = nullptr;      // [lde, Npad] cross-covariance row block (queries x train)
   int64_t E_rows_cap = 0;
@@ -85,10 +86,14 @@ int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, d
                       int* info, int col0, int nvalid);
 int launch_fit_scalars(bgp_handle* h, hipStream_t st, const double* A, int64_t lda, const double* z,
                        int64_t ldz, int64_t n, double* out2);
-int launch_gemvt_partial(bgp_handle* h, hipStream_t st, const double* Lpanel, int64_t lda,
-                         const double* x, int64_t rows, double* part, int* nchunks_out);
-int launch_solve_tile_t(bgp_handle* h, hipStream_t st, const double* inv, const double* z,
-                        int64_t ldz, const double* part, int nchunks, double* alpha_j);
+int launch_trsv_block_fwd(bgp_handle* h, hipStream_t st, const double* Lkk, int64_t lda, const double* invK,
+                          double* w, int nbk);
+int launch_gemv_n_sub(bgp_handle* h, hipStream_t st, const double* P, int64_t lda, const double* z, int nbk,
+                      double* y, int64_t rows);
+int launch_gemv_t_partial(bgp_handle* h, hipStream_t st, const double* P, int64_t lda, const double* x,
+                          int64_t rows, int nbk, double* part, int* nchunks_out);
+int launch_trsv_block_bwd(bgp_handle* h, hipStream_t st, const double* Lkk, int64_t lda, const double* invK,
+                          const double* z, const double* part, int nchunks, int nbk, double* alpha);
 int launch_rowdot(bgp_handle* h, hipStream_t st, const double* E, int64_t lde, int64_t M, int64_t n,
                   const double* vec /*null => E*E*/, double* part, int* nchunks_out);
 int launch_rowdot_finish(bgp_handle* h, hipStream_t st, const double* part, int nchunks, int64_t M,

@@ -6,6 +6,8 @@
 // built on v_mfma_f64_16x16x4_f64.  It serves the SYRK trailing update of the Cholesky, the
 // in-panel updates, the TRSM by inverted 64x64 diagonal tiles, the triangular solve of the
 // query block (posterior variance) and the full-covariance downdate.
+#include <type_traits>
+
 #include "bgp_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -66,7 +68,9 @@ __host__ int64_t gemm_grid_blocks(int nti, int ntj, int lower) {
   return ((total + 7) / 8) * 8 * 64;
 }
 
-template <int TM, int TN, int MODE>
+// ABL != 0 builds ablation variants for tools/gemm_ablate.hip only (bit 0: no operand re-staging,
+// bit 1: no barriers, bit 2: fragments read once) - production always instantiates ABL = 0.
+template <int TM, int TN, int MODE, int ABL = 0, int STAGGER = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc, const double* A,
                                                          int64_t lda, const double* B, int64_t ldb,
                                                          int64_t m, int64_t n, int k, int lower, int nti,
@@ -84,6 +88,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
   if (!map_tile((int64_t)blockIdx.x, nti, ntj, lower, ti, tj)) return;
   const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
 
+  // Two workgroups share a CU (one wave each per SIMD).  Dispatched together they stay in
+  // lock-step, so their prologues/epilogues (no MFMA work) coincide and the matrix pipe idles.
+  // Delay the second resident workgroup of every CU ONCE by about half a tile: from then on
+  // the pair runs anti-phased and one workgroup's fixed overhead hides under the other's MFMAs.
+  if (STAGGER && blockIdx.x >= 256 && blockIdx.x < 512) {
+    const int nsleep = k / 16;  // ~ (k/16 steps * ~8k cycles) / 2, in units of s_sleep 64 (~4k cycles)
+    for (int q = 0; q < nsleep; ++q) __builtin_amdgcn_s_sleep(64);
+  }
+
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave & 1, wj = wave >> 1;
@@ -96,63 +109,42 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
   const double* gA = A + (i0 + ra) + (int64_t)ca * lda;
   const double* gB = B + (j0 + rb) + (int64_t)cb * ldb;
 
+  // Out-of-range rows are clamped to a valid address and zeroed when staged: the loads stay
+  // branch-free, so the whole k-step is one basic block the scheduler can interleave.
+  const double* gA_safe = a_in ? gA : A + (int64_t)ca * lda;
+  const double* gB_safe = b_in ? gB : B + (int64_t)cb * ldb;
   double2 regA[NLA], regB[NLB];
   auto gload = [&](int kt) {
     const int64_t koff = (int64_t)kt * BK;
 #pragma unroll
     for (int q = 0; q < NLA; ++q)
-      regA[q] = a_in ? *reinterpret_cast<const double2*>(gA + (koff + q * CSA) * lda)
-                     : make_double2(0.0, 0.0);
+      regA[q] = *reinterpret_cast<const double2*>(gA_safe + (koff + q * CSA) * lda);
 #pragma unroll
     for (int q = 0; q < NLB; ++q)
-      regB[q] = b_in ? *reinterpret_cast<const double2*>(gB + (koff + q * CSB) * ldb)
-                     : make_double2(0.0, 0.0);
+      regB[q] = *reinterpret_cast<const double2*>(gB_safe + (koff + q * CSB) * ldb);
   };
+  const double za = a_in ? 1.0 : 0.0;
+  const double zb = b_in ? ((MODE == 0) ? -1.0 : 1.0) : 0.0;  // MODE 0 stages -B
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NLA; ++q)
-      *reinterpret_cast<double2*>(&sA[buf][ca + q * CSA][ra]) = regA[q];
+      *reinterpret_cast<double2*>(&sA[buf][ca + q * CSA][ra]) = make_double2(regA[q].x * za, regA[q].y * za);
 #pragma unroll
     for (int q = 0; q < NLB; ++q)
-      *reinterpret_cast<double2*>(&sB[buf][cb + q * CSB][rb]) = regB[q];
+      *reinterpret_cast<double2*>(&sB[buf][cb + q * CSB][rb]) = make_double2(regB[q].x * zb, regB[q].y * zb);
   };
-
-  v4d acc[MJ][MI];
-#pragma unroll
-  for (int a = 0; a < MJ; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-  const int nk = k / BK;
-  gload(0);
-  sstore(0);
-  __syncthreads();
 
   const int l15 = lane & 15, l4 = lane >> 4;
   const int ibase = wi * (TM / 2) + l15, jbase = wj * (TN / 2) + l15;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const int pp = kk * 4 + l4;
-      double fa[MJ], fb[MI];
-#pragma unroll
-      for (int a = 0; a < MJ; ++a) fa[a] = sB[buf][pp][jbase + a * 16];
-#pragma unroll
-      for (int b = 0; b < MI; ++b) fb[b] = sA[buf][pp][ibase + b * 16];
-#pragma unroll
-      for (int a = 0; a < MJ; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
-    }
-    if (kt + 1 < nk) sstore(buf ^ 1);
-    __syncthreads();
-  }
+  const int nk = k / BK;
+  gload(0);
 
-  // epilogue: lane (l15, l4), reg r of tile (a, b) holds (A B^T)(i, j) with
+  // MODE 0: the accumulators START as the C tile and the B operand is staged negated, so the
+  // MFMA chain computes C - A B^T directly: the C reads overlap the first operand loads (one
+  // HBM latency for the whole prologue) and the epilogue is a pure store stream.
+  // lane (l15, l4), reg r of tile (a, b) <-> C(i, j),
   //   i = i0 + wi*TM/2 + b*16 + l15,   j = j0 + wj*TN/2 + a*16 + l4 + 4 r
+  v4d acc[MJ][MI];
 #pragma unroll
   for (int a = 0; a < MJ; ++a) {
 #pragma unroll
@@ -161,73 +153,173 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t j = j0 + wj * (TN / 2) + a * 16 + l4 + 4 * r;
-        if (i < m && j < n) {
-          double* cp = C + i + j * ldc;
-          if (MODE == 0) *cp = *cp - acc[a][b][r];
-          else *cp = acc[a][b][r];
+        acc[a][b][r] = (MODE == 0 && i < m && j < n) ? C[i + j * ldc] : 0.0;
+      }
+    }
+  }
+  sstore(0);
+  if (nk > 1) gload(1);
+  __syncthreads();
+
+  // One barrier per k-step.  Registers always hold tile kt+1 (loaded a full k-step earlier);
+  // it is written to the idle LDS buffer DURING step kt - that buffer was last read in step
+  // kt-1, behind the previous barrier - and the loads of tile kt+2 are issued right after.
+  // The staging instructions are placed behind the first fragment reads and spread one per
+  // MFMA (sched_group_barrier), so they issue in the shadow of the 64-cycle MFMAs instead of
+  // stalling the matrix pipe at the top of the step.
+  auto kstep = [&](int kt, auto do_store, auto do_load) {
+    const int buf = (ABL & 1) ? 0 : (kt & 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int pp = kk * 4 + l4;
+      double fa[MJ], fb[MI];
+#pragma unroll
+      for (int a = 0; a < MJ; ++a) fa[a] = sB[buf][pp][jbase + a * 16];
+#pragma unroll
+      for (int b = 0; b < MI; ++b) fb[b] = sA[buf][pp][ibase + b * 16];
+      if (kk == 0 && !(ABL & 1)) {
+        if (decltype(do_store)::value) sstore(buf ^ 1);
+        if (decltype(do_load)::value) gload(kt + 2);
+      }
+#pragma unroll
+      for (int a = 0; a < MJ; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      if (kk == 0 && !(ABL & 1) && !(ABL & 8)) {
+        if (decltype(do_store)::value) {
+#pragma unroll
+          for (int q = 0; q < NLA + NLB; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 DS write
+          }
         }
+        if (decltype(do_load)::value) {
+#pragma unroll
+          for (int q = 0; q < NLA + NLB; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+          }
+        }
+      }
+    }
+    if (!(ABL & 2)) __syncthreads();
+  };
+  {
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) kstep(kt, std::true_type{}, std::true_type{});
+    if (kt + 1 < nk) { kstep(kt, std::true_type{}, std::false_type{}); ++kt; }
+    if (kt < nk) kstep(kt, std::false_type{}, std::false_type{});
+  }
+
+  // epilogue: pure stores
+#pragma unroll
+  for (int a = 0; a < MJ; ++a) {
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+      const int64_t i = i0 + wi * (TM / 2) + b * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + wj * (TN / 2) + a * 16 + l4 + 4 * r;
+        if (i < m && j < n) C[i + j * ldc] = acc[a][b][r];
       }
     }
   }
 }
 
 // ---- 64x64 diagonal tile: Cholesky + explicit inverse ------------------------------------
-// One workgroup.  The tile lives in LDS column-major (s[c][r] = A(r,c)): column walks are
-// contiguous and pivot-row reads are broadcasts, so the factorisation is bank-conflict free.
-// info (global, 0 = ok) receives col0 + j + 1 for the first non-positive pivot.
-__global__ __launch_bounds__(256) void potrf_tile_kernel(double* __restrict__ Ajj, int64_t lda,
-                                                         double* __restrict__ inv,
-                                                         int* __restrict__ info, int col0) {
-  __shared__ double s[64][64];
-  __shared__ double sx[64][64];
-  __shared__ int s_fail;
-  const int tid = threadIdx.x;
-  const int row = tid & 63, wv = tid >> 6;
-  if (tid == 0) s_fail = 0;
-  for (int idx = tid; idx < 4096; idx += 256) {
-    const int r = idx & 63, c = idx >> 6;
-    s[c][r] = (r >= c) ? Ajj[r + (int64_t)c * lda] : 0.0;
-  }
-  __syncthreads();
+// Register-resident: wave 0 holds the tile with lane = row, register = column (128 VGPRs) and
+// runs the right-looking column Cholesky with v_readlane broadcasts - no LDS traffic and no
+// barriers on the 64-step critical path.  Then 8 waves compute 8 columns each of X = L^-1 by
+// forward substitution in the same lane = row layout.  Fully unrolled: every register index
+// and every readlane lane-select is a compile-time constant.
+__device__ __forceinline__ double readlane_d(double v, int srclane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, srclane);
+  hi = __builtin_amdgcn_readlane(hi, srclane);
+  return __hiloint2double(hi, lo);
+}
 
-  for (int j = 0; j < 64; ++j) {
-    const double ajj = s[j][j];
-    if (!(ajj > 0.0) && tid == 0 && s_fail == 0) s_fail = j + 1;  // also catches NaN
-    const double d = __builtin_sqrt(ajj);
-    const double rd = 1.0 / d;
-    __syncthreads();  // everybody has read the pivot
-    if (tid > j && tid < 64) s[j][tid] *= rd;
-    if (tid == j) s[j][j] = d;
-    __syncthreads();
-    // rank-1 update of the trailing lower triangle: lane <-> row, wave w takes columns j+1+w (+4..)
-    const double lrj = s[j][row];
-    for (int c = j + 1 + wv; c < 64; c += 4)
-      if (row >= c) s[c][row] = __builtin_fma(-lrj, s[j][c], s[c][row]);
-    __syncthreads();
-  }
+// 1/sqrt(p) to ~1 ulp: v_rsq_f64 seed (~2^-26) + two Newton steps; p must be a normal number
+__device__ __forceinline__ double rsqrt_newton(double p) {
+  double y = __builtin_amdgcn_rsq(p);
+  double hp = 0.5 * p;
+  y = y * __builtin_fma(-hp * y, y, 1.5);
+  y = y * __builtin_fma(-hp * y, y, 1.5);
+  return y;
+}
 
-  for (int idx = tid; idx < 4096; idx += 256) {
-    const int r = idx & 63, c = idx >> 6;
-    if (r >= c) Ajj[r + (int64_t)c * lda] = s[c][r];
-  }
-  if (tid == 0 && s_fail != 0) atomicCAS(info, 0, col0 + s_fail);
-
-  // X = L^-1, one thread per column c (sx[p][c] = X(p,c)):
-  //   x_c = 1/L_cc,  x_i = -(sum_{p=c}^{i-1} L_ip x_p) / L_ii
-  if (tid < 64) {
-    const int c = tid;
-    for (int i = 0; i < c; ++i) sx[i][c] = 0.0;
-    sx[c][c] = 1.0 / s[c][c];
-    for (int i = c + 1; i < 64; ++i) {
-      double acc = 0.0;
-      for (int p = c; p < i; ++p) acc = __builtin_fma(s[p][i], sx[p][c], acc);
-      sx[i][c] = -acc / s[i][i];
+template <int W>
+__device__ __forceinline__ void inv_slice(const double (*s)[64], double* __restrict__ inv, int lane) {
+  constexpr int C0 = 8 * W;
+  double Lr[64];
+#pragma unroll
+  for (int p = C0; p < 64; ++p) Lr[p] = s[p][lane];  // L(lane, p); zero above the diagonal
+  const double rd_own = 1.0 / s[lane][lane];
+  double x[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) x[cc] = (lane == C0 + cc) ? 1.0 : 0.0;
+#pragma unroll
+  for (int p = C0; p < 64; ++p) {
+    const double rdp = readlane_d(rd_own, p);
+    const double f = (lane == p) ? rdp : 1.0;
+    const double lm = (lane == p) ? 0.0 : Lr[p];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      if (C0 + cc <= p) {
+        x[cc] *= f;                                // lane p: X(p,c) = acc_p / L_pp
+        const double xpc = readlane_d(x[cc], p);
+        x[cc] = __builtin_fma(-lm, xpc, x[cc]);    // rows below: acc_i -= L(i,p) X(p,c)
+      }
     }
   }
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) inv[lane + (C0 + cc) * 64] = x[cc];
+}
+
+__global__ __launch_bounds__(512) void potrf_tile_kernel(double* __restrict__ Ajj, int64_t lda,
+                                                         double* __restrict__ inv,
+                                                         int* __restrict__ info, int col0) {
+  __shared__ double s[64][64];  // s[c][r] = L(r, c), zeros above the diagonal
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave == 0) {
+    double a[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) a[c] = (c <= lane) ? Ajj[lane + (int64_t)c * lda] : 0.0;
+    int fail = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const double piv = readlane_d(a[j], j);
+      if (!(piv > 0.0) && fail == 0) fail = j + 1;  // also catches NaN
+      const double rd = rsqrt_newton(piv);
+      double d = piv * rd;
+      d = __builtin_fma(0.5 * rd, __builtin_fma(-d, d, piv), d);  // one correction: d = sqrt(piv)
+      const double lij = (lane > j) ? a[j] * rd : 0.0;
+#pragma unroll
+      for (int c = j + 1; c < 64; ++c) {
+        const double lcj = readlane_d(lij, c);
+        a[c] = __builtin_fma(-lij, lcj, a[c]);
+      }
+      a[j] = (lane == j) ? d : lij;
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      s[c][lane] = a[c];
+      if (lane >= c) Ajj[lane + (int64_t)c * lda] = a[c];
+    }
+    if (lane == 0 && fail != 0) atomicCAS(info, 0, col0 + fail);
+  }
   __syncthreads();
-  for (int idx = tid; idx < 4096; idx += 256) {
-    const int c = idx & 63, r = idx >> 6;
-    inv[r + c * 64] = sx[r][c];
+  switch (wave) {
+    case 0: inv_slice<0>(s, inv, lane); break;
+    case 1: inv_slice<1>(s, inv, lane); break;
+    case 2: inv_slice<2>(s, inv, lane); break;
+    case 3: inv_slice<3>(s, inv, lane); break;
+    case 4: inv_slice<4>(s, inv, lane); break;
+    case 5: inv_slice<5>(s, inv, lane); break;
+    case 6: inv_slice<6>(s, inv, lane); break;
+    default: inv_slice<7>(s, inv, lane); break;
   }
 }
 
@@ -258,39 +350,149 @@ __global__ __launch_bounds__(1024) void fit_scalars_kernel(const double* __restr
   }
 }
 
-// ---- backward solve  alpha = L^-T z, one 64-column block at a time ---------------------------
-// part[chunk][c] = sum_{r in chunk} L[r, c] x[r]  for the 64 columns of the panel.
-constexpr int GV_ROWS = 4096;  // rows per workgroup
-__global__ __launch_bounds__(256) void gemvt_partial_kernel(const double* __restrict__ Lp, int64_t lda,
-                                                            const double* __restrict__ x, int64_t rows,
-                                                            double* __restrict__ part) {
+// ---- triangular solves with ONE right-hand side (z = L^-1 y, alpha = L^-T z) ------------------
+// Two-level like the factorisation: per outer panel one single-workgroup kernel solves the
+// nbk x nbk diagonal block (64-wide steps using the stored tile inverses) and one streaming
+// GEMV kernel applies the panel to the rest of the vector.  HBM-bound: L is read once per solve.
+constexpr int TRSV_MAX_NB = 2048;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;
+}
+
+// in place: w[0..nbk) <- L_KK^-1 w.   One workgroup of 512 threads.
+__global__ __launch_bounds__(512) void trsv_block_fwd_kernel(const double* __restrict__ Lkk, int64_t lda,
+                                                             const double* __restrict__ invK,
+                                                             double* __restrict__ w, int nbk) {
+  __shared__ double sw[TRSV_MAX_NB];
+  __shared__ double sp[8][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < nbk; i += 512) sw[i] = w[i];
+  __syncthreads();
+  for (int j = 0; j < nbk; j += 64) {
+    // z_j = inv_j * w_j : wave q sums columns [8q, 8q+8) for all 64 rows (lane = row, coalesced)
+    const double* inv_j = invK + (int64_t)(j / 64) * 4096;
+    {
+      double acc = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const int c = wave * 8 + cc;
+        acc = __builtin_fma(inv_j[lane + c * 64], sw[j + c], acc);
+      }
+      sp[wave][lane] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double z = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) z += sp[q][tid];
+      sw[j + tid] = z;
+    }
+    __syncthreads();
+    // rows below inside the block: w_i -= sum_c L(i, j+c) z_c
+    for (int i = j + 64 + tid; i < nbk; i += 512) {
+      double acc = 0.0;
+      const double* Lrow = Lkk + i + (int64_t)j * lda;
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) acc = __builtin_fma(Lrow[(int64_t)c * lda], sw[j + c], acc);
+      sw[i] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nbk; i += 512) w[i] = sw[i];
+}
+
+// y[r] -= sum_{c<nbk} P[r, c] z[c]  for r < rows.  Workgroup = 64 rows x 4 column quarters.
+__global__ __launch_bounds__(256) void gemv_n_sub_kernel(const double* __restrict__ P, int64_t lda,
+                                                         const double* __restrict__ z, int nbk,
+                                                         double* __restrict__ y, int64_t rows) {
+  __shared__ double sz[TRSV_MAX_NB];
+  __shared__ double sp[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < nbk; i += 256) sz[i] = z[i];
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+  const int cq = nbk / 4;  // nbk is a multiple of 64
+  double acc = 0.0;
+  if (r < rows) {
+    const double* Pr = P + r + (int64_t)(wave * cq) * lda;
+    const double* zz = sz + wave * cq;
+#pragma unroll 8
+    for (int c = 0; c < cq; ++c) acc = __builtin_fma(Pr[(int64_t)c * lda], zz[c], acc);
+  }
+  sp[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && r < rows) y[r] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
+}
+
+// part[chunk * nbk + c] = sum_{r in chunk} P[r, c] x[r];  grid = (row chunks of 1024, nbk / 64)
+constexpr int GT_ROWS = 1024;
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* __restrict__ P, int64_t lda,
+                                                             const double* __restrict__ x, int64_t rows,
+                                                             int nbk, double* __restrict__ part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * GV_ROWS;
-  const int64_t r1 = (r0 + GV_ROWS < rows) ? r0 + GV_ROWS : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * GT_ROWS;
+  double xv[GT_ROWS / 64];
+#pragma unroll
+  for (int t = 0; t < GT_ROWS / 64; ++t) {
+    const int64_t r = r0 + lane + 64 * t;
+    xv[t] = (r < rows) ? x[r] : 0.0;
+  }
   for (int cc = 0; cc < 16; ++cc) {
-    const int c = wave * 16 + cc;
-    const double* col = Lp + (int64_t)c * lda;
+    const int c = blockIdx.y * 64 + wave * 16 + cc;
+    const double* col = P + (int64_t)c * lda;
     double acc = 0.0;
-    for (int64_t r = r0 + lane; r < r1; r += 64) acc = __builtin_fma(col[r], x[r], acc);
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if (lane == 0) part[(int64_t)blockIdx.x * 64 + c] = acc;
+#pragma unroll
+    for (int t = 0; t < GT_ROWS / 64; ++t) {
+      const int64_t r = r0 + lane + 64 * t;
+      const double v = (r < rows) ? col[r] : 0.0;
+      acc = __builtin_fma(v, xv[t], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) part[(int64_t)blockIdx.x * nbk + c] = acc;
   }
 }
 
-// w = z_j - sum_chunks part;  alpha_j = inv^T w
-__global__ __launch_bounds__(64) void solve_tile_t_kernel(const double* __restrict__ inv,
-                                                          const double* __restrict__ z, int64_t ldz,
-                                                          const double* __restrict__ part, int nchunks,
-                                                          double* __restrict__ alpha_j) {
-  __shared__ double w[64];
-  const int c = threadIdx.x;
-  double v = z[(int64_t)c * ldz];
-  for (int q = 0; q < nchunks; ++q) v -= part[(int64_t)q * 64 + c];
-  w[c] = v;
+// alpha_K <- L_KK^-T (z_K - sum_chunks part).   One workgroup of 512 threads.
+__global__ __launch_bounds__(512) void trsv_block_bwd_kernel(const double* __restrict__ Lkk, int64_t lda,
+                                                             const double* __restrict__ invK,
+                                                             const double* __restrict__ z,
+                                                             const double* __restrict__ part, int nchunks,
+                                                             int nbk, double* __restrict__ alpha) {
+  __shared__ double sw[TRSV_MAX_NB];
+  __shared__ double sv[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < nbk; c += 512) {
+    double v = z[c];
+    for (int q = 0; q < nchunks; ++q) v -= part[(int64_t)q * nbk + c];
+    sw[c] = v;
+  }
   __syncthreads();
-  double acc = 0.0;
-  for (int p = c; p < 64; ++p) acc = __builtin_fma(inv[p + c * 64], w[p], acc);
-  alpha_j[c] = acc;
+  for (int j = nbk - 64; j >= 0; j -= 64) {
+    // v_c = w_{j+c} - sum_{i >= j+64} L(i, j+c) alpha_i   (wave q: columns 8q..8q+7, lanes over rows)
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c = wave * 8 + cc;
+      const double* col = Lkk + (int64_t)(j + c) * lda;
+      double acc = 0.0;
+      for (int i = j + 64 + lane; i < nbk; i += 64) acc = __builtin_fma(col[i], sw[i], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) sv[c] = sw[j + c] - acc;
+    }
+    __syncthreads();
+    // alpha_{j+q} = sum_{p >= q} inv(p, q) v_p   (inv is zero above the diagonal)
+    const double* inv_j = invK + (int64_t)(j / 64) * 4096;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      const int q = wave * 8 + qq;
+      double acc = wave_sum(inv_j[lane + q * 64] * sv[lane]);
+      if (lane == 0) sw[j + q] = acc;
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < nbk; c += 512) alpha[c] = sw[c];
 }
 
 // ---- row-wise reductions over the query block E[M, n] (column-major, rows contiguous) ---------
@@ -406,7 +608,7 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
 
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv, int* info,
                       int col0, int /*nvalid*/) {
-  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
+  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), 0, st, Ajj, lda, inv, info, col0);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }
@@ -418,19 +620,39 @@ int launch_fit_scalars(bgp_handle* h, hipStream_t st, const double* A, int64_t l
   return 0;
 }
 
-int launch_gemvt_partial(bgp_handle* h, hipStream_t st, const double* Lpanel, int64_t lda,
-                         const double* x, int64_t rows, double* part, int* nchunks_out) {
-  const int nch = (int)((rows + GV_ROWS - 1) / GV_ROWS);
-  *nchunks_out = nch;
-  if (nch == 0) return 0;
-  hipLaunchKernelGGL(gemvt_partial_kernel, dim3(nch), dim3(256), 0, st, Lpanel, lda, x, rows, part);
+int launch_trsv_block_fwd(bgp_handle* h, hipStream_t st, const double* Lkk, int64_t lda, const double* invK,
+                          double* w, int nbk) {
+  if (nbk > TRSV_MAX_NB) return bgp_fail(h, -1, "nb_outer=%d exceeds the TRSV limit %d", nbk, TRSV_MAX_NB);
+  hipLaunchKernelGGL(trsv_block_fwd_kernel, dim3(1), dim3(512), 0, st, Lkk, lda, invK, w, nbk);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }
 
-int launch_solve_tile_t(bgp_handle* h, hipStream_t st, const double* inv, const double* z, int64_t ldz,
-                        const double* part, int nchunks, double* alpha_j) {
-  hipLaunchKernelGGL(solve_tile_t_kernel, dim3(1), dim3(64), 0, st, inv, z, ldz, part, nchunks, alpha_j);
+int launch_gemv_n_sub(bgp_handle* h, hipStream_t st, const double* P, int64_t lda, const double* z, int nbk,
+                      double* y, int64_t rows) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(gemv_n_sub_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st, P, lda, z, nbk, y,
+                     rows);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_gemv_t_partial(bgp_handle* h, hipStream_t st, const double* P, int64_t lda, const double* x,
+                          int64_t rows, int nbk, double* part, int* nchunks_out) {
+  const int nch = (int)((rows + GT_ROWS - 1) / GT_ROWS);
+  *nchunks_out = nch;
+  if (nch == 0) return 0;
+  hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)nch, (unsigned)(nbk / 64)), dim3(256), 0, st, P, lda,
+                     x, rows, nbk, part);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_trsv_block_bwd(bgp_handle* h, hipStream_t st, const double* Lkk, int64_t lda, const double* invK,
+                          const double* z, const double* part, int nchunks, int nbk, double* alpha) {
+  if (nbk > TRSV_MAX_NB) return bgp_fail(h, -1, "nb_outer=%d exceeds the TRSV limit %d", nbk, TRSV_MAX_NB);
+  hipLaunchKernelGGL(trsv_block_bwd_kernel, dim3(1), dim3(512), 0, st, Lkk, lda, invK, z, part, nchunks, nbk,
+                     alpha);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py - exact-GP fit+predict on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one synthetic cell: covariance fill over
+(time, I, SOC, T) inputs -> jittered blocked Cholesky -> z, alpha, LML -> cross fill,
+posterior mean and variance at M = 300 query points.  Inputs (X, y, Xq) are resident in HBM
+before the timed region starts; results stay on the device.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 40000] [--kernel battgp]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU: every rank fits its OWN cell
+(the reference's "8-cell pack" = independent GPs, src/batt_models/battgp_full.py:41-60), no
+data-path collective; barrier + max-over-ranks timing; value = whole-job GFLOP/s.
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak (= 256 CU x 2.4 GHz x 128 flop/clk)
+PEAK_HBM_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_flop(n: int, m: int) -> float:
+    """N^3/3 (Cholesky) + N^2 M (predictive TRSM) + 2 N^2 (two TRSV)."""
+    return n**3 / 3.0 + float(n) * n * m + 2.0 * n * n
+
+
+def cpu_baseline(kernel_id, hyp, n_cpu: int, m: int, seed: int):
+    """Oracle (numpy fill + LAPACK dpotrf/dtrtrs) timed on the host cores: baseline only."""
+    from threadpoolctl import threadpool_info
+
+    from battgp_amd import synthetic
+    from oracle.exact_gp import OracleGP
+
+    x, y = synthetic.make_cell_data(n_cpu, seed=seed)
+    xq = synthetic.make_query(x, m)
+    t0 = time.perf_counter()
+    gp = OracleGP(kernel_id, hyp, x, y).fit()
+    gp.predict(xq)
+    dt = time.perf_counter() - t0
+    threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    return {
+        "value": algorithmic_flop(n_cpu, m) / dt / 1e9,
+        "unit": "GFLOP/s",
+        "cores": int(threads),
+        "host_cpus": os.cpu_count(),
+        "kind": "port",
+        "seconds": dt,
+        "sample": f"same workload at N={n_cpu} (one fit+predict, M={m}); numpy fill + LAPACK dpotrf/dtrtrs via scipy/OpenBLAS",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=40000, help="training points per cell (configs[1]: 40 000)")
+    ap.add_argument("--m", type=int, default=300, help="query points (battgp_full.py:98)")
+    ap.add_argument("--kernel", default="battgp", choices=["battgp", "matern32"])
+    ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
+    ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-residuals", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from battgp_amd import KERNEL_BATTGP, KERNEL_MATERN32, synthetic
+    from battgp_amd.engine import ExactGPEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(
+            f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
+        )
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    kernel_id, hyp = (
+        (KERNEL_BATTGP, synthetic.HYP_BATTGP) if args.kernel == "battgp" else (KERNEL_MATERN32, synthetic.HYP_MATERN32)
+    )
+    n, m = args.n, args.m
+    # every rank = a different cell (different seed), same size: weak scaling, no collective
+    x, y = synthetic.make_cell_data(n, seed=n + rank)
+    xq = synthetic.make_query(x, m)
+    dev = torch.device("cuda", local_rank)
+    tx = torch.from_numpy(x).to(dev)
+    ty = torch.from_numpy(y).to(dev)
+    txq = torch.from_numpy(xq).to(dev)
+    tmean = torch.empty(m, dtype=torch.float64, device=dev)
+    tvar = torch.empty(m, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    eng = ExactGPEngine(kernel_id, hyp, device=local_rank)
+    if args.nb > 0:
+        eng.set_options(nb_outer=args.nb)
+
+    def step():
+        eng.fit_device(tx.data_ptr(), ty.data_ptr(), n, 4)
+        eng.predict_device(txq.data_ptr(), m, tmean.data_ptr(), tvar.data_ptr(), 1e-10)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    phases = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()  # every C-ABI call returns only after its own stream has drained
+        phases.append(eng.phase_times())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    resid = None
+    if not args.no_residuals:
+        resid = eng.residuals(256)  # on-device correctness evidence at the benchmarked size
+    mean_host = tmean.cpu().numpy()
+    lml, jitter = eng.lml, eng.jitter
+    mem_bytes = eng.device_bytes()
+    eng.close()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        flop = algorithmic_flop(n, m)
+        value = world * flop * args.steps / elapsed / 1e9
+        avg = {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
+        trail_tflops = avg["trail_flop"] / (avg["trail_ms"] * 1e-3) / 1e12 if avg["trail_ms"] > 0 else 0.0
+        fill_gbs = avg["fill_bytes"] / (avg["fill_ms"] * 1e-3) / 1e9 if avg["fill_ms"] > 0 else 0.0
+        potrf_tflops = (n**3 / 3.0) / (avg["potrf_ms"] * 1e-3) / 1e12 if avg["potrf_ms"] > 0 else 0.0
+        out = {
+            "metric": "exact-GP fit+predict throughput (fp64)",
+            "value": value,
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"full_gp, {'Wiener+ARD-RBF (reference full_gp kernel)' if args.kernel == 'battgp' else 'Matern-3/2 ARD'}, "
+                f"N={n} synthetic 4-D inputs, M={m} queries, one cell per GPU",
+                "n": n,
+                "m": m,
+                "kernel": args.kernel,
+                "flop_per_step": flop,
+                "parallelism": f"{world} independent cells" if world > 1 else "1 cell",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "gemm_nt_kernel<128,128,0> (rank-NB SYRK trailing update of the blocked Cholesky)",
+                "achieved": trail_tflops,
+                "peak": PEAK_FP64_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": trail_tflops / PEAK_FP64_MFMA_TFLOPS,
+                "traffic": None,
+                "launches_per_step": None,
+                "note": "sum of algorithmic flop m(m+1)k of the outer trailing updates / sum of their HIP-event durations",
+            },
+            "roofline_fill": {
+                "bound": "hbm",
+                "kernel": "fill_kernel (lower triangle, 4N(N+1) algorithmic bytes)",
+                "achieved": fill_gbs,
+                "peak": PEAK_HBM_GBS,
+                "unit": "GB/s",
+                "frac": fill_gbs / PEAK_HBM_GBS,
+            },
+            "phases_ms": {k: avg[k] for k in ("h2d_ms", "fill_ms", "potrf_ms", "solve_ms", "cross_ms", "var_ms", "d2h_ms", "trail_ms")},
+            "potrf_tflops": potrf_tflops,
+            "potrf_frac_of_peak": potrf_tflops / PEAK_FP64_MFMA_TFLOPS,
+            "lml": lml,
+            "jitter": jitter,
+            "residuals": {"rel_solve": resid[0], "max_llt": resid[1]} if resid else None,
+            "mean_first": [float(v) for v in mean_host[:3]],
+            "device_bytes": mem_bytes,
+        }
+        if args.cpu_n > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(kernel_id, hyp, args.cpu_n, m, seed=args.cpu_n)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
