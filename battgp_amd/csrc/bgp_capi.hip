@@ -133,12 +133,12 @@ int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t ld
     const int64_t rows_below = n - (j + BGP_IB);
     if (rows_below > 0) {
       double* A21 = A + (j + BGP_IB) + j * lda;
-      rc = launch_gemm_nt(h, st, 1, 64, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0);
+      rc = launch_gemm_nt(h, st, 1, 64, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0, dinfo);
       if (rc) return rc;
       const int64_t ncols = K0 + nbk - (j + BGP_IB);
       if (ncols > 0) {
         rc = launch_gemm_nt(h, st, 0, 128, A + (j + BGP_IB) + (j + BGP_IB) * lda, lda, A21, lda, A21, lda,
-                            rows_below, ncols, BGP_IB, 1);
+                            rows_below, ncols, BGP_IB, 1, dinfo);
         if (rc) return rc;
       }
     }
@@ -227,7 +227,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t ld
       double* P = A + K1 + K0 * lda;
       if (!la) {
         if ((rc = tt.begin(st))) return rc;
-        rc = launch_gemm_nt(h, st, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail, rows_trail, nbk, 1);
+        rc = launch_gemm_nt(h, st, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail, rows_trail, nbk, 1, dinfo);
         if (rc) return rc;
         if ((rc = tt.end(st, (double)rows_trail, (double)rows_trail, (double)nbk, true))) return rc;
       } else {
@@ -240,7 +240,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t ld
         // la(k) on sp rewrites columns that rest(k-1) also updated: order it after rest(k-1)
         if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + 2 * (size_t)(step - 1)], 0));
         if ((rc = tt.begin(sp))) return rc;
-        rc = launch_gemm_nt(h, sp, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail, nbn, nbk, 1);
+        rc = launch_gemm_nt(h, sp, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail, nbn, nbk, 1, dinfo);
         if (rc) return rc;
         if ((rc = tt.end(sp, (double)rows_trail, (double)nbn, (double)nbk, false))) return rc;
         // rest(k) on st: everything right of the next panel
@@ -248,19 +248,18 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t ld
         if (rows_rest > 0) {
           const double* P2 = A + K2 + K0 * lda;
           if ((rc = tt.begin(st))) return rc;
-          rc = launch_gemm_nt(h, st, 0, 128, A + K2 + K2 * lda, lda, P2, lda, P2, lda, rows_rest, rows_rest, nbk, 1);
+          // stagger the first round when the launch spans many rounds of equal tiles (see kernel)
+          const int64_t nt_rest = (rows_rest + 127) / 128;
+          const int64_t rounds = nt_rest * (nt_rest + 1) / 2 / 512;
+          const int stagger = (rounds >= 8) ? (int)((nbk / 16) * 3.6 / 8.0 / 1.7 + 1.0) : 0;
+          rc = launch_gemm_nt(h, st, 0, 128, A + K2 + K2 * lda, lda, P2, lda, P2, lda, rows_rest, rows_rest, nbk, 1,
+                              dinfo, stagger);
           if (rc) return rc;
           if ((rc = tt.end(st, (double)rows_rest, (double)rows_rest, (double)nbk, true))) return rc;
         }
         if ((rc = sync_event(h, 2 + 2 * (size_t)step, &ev))) return rc;
         BGP_HIP(h, hipEventRecord(ev, st));
       }
-    }
-    // early exit on a failed pivot: look at the flag every 8 outer steps
-    if ((step & 7) == 7) {
-      int info = 0;
-      if ((rc = check_info(h, st, la ? sp : nullptr, dinfo, &info))) return rc;
-      if (info != 0) break;
     }
   }
   int info = 0;
@@ -527,11 +526,9 @@ int bgp_create(bgp_handle** out, int device) {
   } while (0)
   CREATE_HIP(hipSetDevice(device));
   CREATE_HIP(hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking));
-  {
-    int prio_lo = 0, prio_hi = 0;
-    CREATE_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    CREATE_HIP(hipStreamCreateWithPriority(&h->s_aux, hipStreamNonBlocking, prio_hi));
-  }
+  // default priority on purpose: on MI355X/ROCm 7.2 a high-priority stream was measured to get CU
+  // slots LATER (99 us vs 12 us) than a default one next to a staggered big grid (tools/prio_probe.hip)
+  CREATE_HIP(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
   CREATE_HIP(hipEventCreate(&h->ev_a));
   CREATE_HIP(hipEventCreate(&h->ev_b));
   CREATE_HIP(hipEventCreate(&h->ev_c));

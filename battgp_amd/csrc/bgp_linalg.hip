@@ -70,11 +70,12 @@ __host__ int64_t gemm_grid_blocks(int nti, int ntj, int lower) {
 
 // ABL != 0 builds ablation variants for tools/gemm_ablate.hip only (bit 0: no operand re-staging,
 // bit 1: no barriers, bit 2: fragments read once) - production always instantiates ABL = 0.
-template <int TM, int TN, int MODE, int ABL = 0, int STAGGER = 0>
+template <int TM, int TN, int MODE, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc, const double* A,
                                                          int64_t lda, const double* B, int64_t ldb,
                                                          int64_t m, int64_t n, int k, int lower, int nti,
-                                                         int ntj) {
+                                                         int ntj, const int* __restrict__ abort_flag,
+                                                         int stagger) {
   constexpr int LDA_S = TM + 16;  // (ld % 32 == 16) => the two 16-lane groups of a ds_read_b64
   constexpr int LDB_S = TN + 16;  //  half-wave hit disjoint bank halves: conflict-free
   constexpr int MI = TM / 32, MJ = TN / 32;          // 16x16 MFMA tiles per wave along i / j
@@ -88,13 +89,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
   if (!map_tile((int64_t)blockIdx.x, nti, ntj, lower, ti, tj)) return;
   const int64_t i0 = (int64_t)ti * TM, j0 = (int64_t)tj * TN;
 
-  // Two workgroups share a CU (one wave each per SIMD).  Dispatched together they stay in
-  // lock-step, so their prologues/epilogues (no MFMA work) coincide and the matrix pipe idles.
-  // Delay the second resident workgroup of every CU ONCE by about half a tile: from then on
-  // the pair runs anti-phased and one workgroup's fixed overhead hides under the other's MFMAs.
-  if (STAGGER && blockIdx.x >= 256 && blockIdx.x < 512) {
-    const int nsleep = k / 16;  // ~ (k/16 steps * ~8k cycles) / 2, in units of s_sleep 64 (~4k cycles)
-    for (int q = 0; q < nsleep; ++q) __builtin_amdgcn_s_sleep(64);
+  // A failed pivot earlier in the factorisation poisons the rest of the enqueued pipeline:
+  // every later kernel sees the flag and returns at once (no host round trip needed).
+  if (abort_flag != nullptr && *abort_flag != 0) return;
+
+  // Equal tiles finish in lock-step "rounds": CU slots would free only every ~130 us and the
+  // dependent panel kernels of the look-ahead stream would advance one kernel per round.
+  // Spreading the start of the first resident workgroups over 8 phases makes slots free
+  // continuously for the whole launch (measured: a waiting kernel gets a slot in ~12 us
+  // instead of ~205 us).  Speed only; no effect on results.
+  if (stagger > 0 && blockIdx.x < 512) {
+    const int ns = (int)((blockIdx.x >> 3) & 7) * stagger;  // b % 8 selects the XCD: vary the phase WITHIN each XCD
+    for (int q = 0; q < ns; ++q) __builtin_amdgcn_s_sleep(64);
   }
 
   const int tid = threadIdx.x;
@@ -230,8 +236,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
 // ---- 64x64 diagonal tile: Cholesky + explicit inverse ------------------------------------
 // Register-resident: wave 0 holds the tile with lane = row, register = column (128 VGPRs) and
 // runs the right-looking column Cholesky with v_readlane broadcasts - no LDS traffic and no
-// barriers on the 64-step critical path.  Then 8 waves compute 8 columns each of X = L^-1 by
-// forward substitution in the same lane = row layout.  Fully unrolled: every register index
+// barriers on the 64-step critical path.  Then 4 waves compute 16 columns each of X = L^-1 by
+// forward substitution in the same lane = row layout (4 waves x 16 columns: the kernel's footprint
+// - 4 waves, <= 256 VGPRs, 32 KB LDS - equals one GEMM workgroup, so it fits the half-CU slot a
+// finishing trailing-update workgroup frees and is not starved under look-ahead).  Fully unrolled: every register index
 // and every readlane lane-select is a compile-time constant.
 __device__ __forceinline__ double readlane_d(double v, int srclane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -251,21 +259,19 @@ __device__ __forceinline__ double rsqrt_newton(double p) {
 
 template <int W>
 __device__ __forceinline__ void inv_slice(const double (*s)[64], double* __restrict__ inv, int lane) {
-  constexpr int C0 = 8 * W;
-  double Lr[64];
-#pragma unroll
-  for (int p = C0; p < 64; ++p) Lr[p] = s[p][lane];  // L(lane, p); zero above the diagonal
+  constexpr int NC = 16;  // columns per wave (4 waves)
+  constexpr int C0 = NC * W;
   const double rd_own = 1.0 / s[lane][lane];
-  double x[8];
+  double x[NC];
 #pragma unroll
-  for (int cc = 0; cc < 8; ++cc) x[cc] = (lane == C0 + cc) ? 1.0 : 0.0;
+  for (int cc = 0; cc < NC; ++cc) x[cc] = (lane == C0 + cc) ? 1.0 : 0.0;
 #pragma unroll
   for (int p = C0; p < 64; ++p) {
     const double rdp = readlane_d(rd_own, p);
     const double f = (lane == p) ? rdp : 1.0;
-    const double lm = (lane == p) ? 0.0 : Lr[p];
+    const double lm = (lane == p) ? 0.0 : s[p][lane];  // L(lane, p); zero above the diagonal
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
+    for (int cc = 0; cc < NC; ++cc) {
       if (C0 + cc <= p) {
         x[cc] *= f;                                // lane p: X(p,c) = acc_p / L_pp
         const double xpc = readlane_d(x[cc], p);
@@ -274,19 +280,28 @@ __device__ __forceinline__ void inv_slice(const double (*s)[64], double* __restr
     }
   }
 #pragma unroll
-  for (int cc = 0; cc < 8; ++cc) inv[lane + (C0 + cc) * 64] = x[cc];
+  for (int cc = 0; cc < NC; ++cc) inv[lane + (C0 + cc) * 64] = x[cc];
 }
 
-__global__ __launch_bounds__(512) void potrf_tile_kernel(double* __restrict__ Ajj, int64_t lda,
-                                                         double* __restrict__ inv,
-                                                         int* __restrict__ info, int col0) {
-  __shared__ double s[64][64];  // s[c][r] = L(r, c), zeros above the diagonal
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+__global__ __launch_bounds__(256, 2) void potrf_tile_kernel(double* __restrict__ Ajj, int64_t lda,
+                                                            double* __restrict__ inv,
+                                                            int* __restrict__ info, int col0) {
+  __shared__ double s[64][64];  // s[c][r] = A(r, c) on entry, L(r, c) (zero above the diagonal) after
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (*info != 0) return;  // an earlier tile already failed: the whole pipeline is void
+  // coalesced tile load through LDS (also keeps 64 column addresses out of the VGPR budget)
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int r = idx & 63, c = idx >> 6;
+    s[c][r] = Ajj[r + (int64_t)c * lda];
+  }
+  __syncthreads();
   if (wave == 0) {
+    // The strict upper triangle holds don't-care values: they are updated like everything else
+    // but never read as a pivot or broadcast, so they cannot contaminate the factor.
     double a[64];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) a[c] = (c <= lane) ? Ajj[lane + (int64_t)c * lda] : 0.0;
+    for (int c = 0; c < 64; ++c) a[c] = s[c][lane];
     int fail = 0;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
@@ -304,22 +319,19 @@ __global__ __launch_bounds__(512) void potrf_tile_kernel(double* __restrict__ Aj
       a[j] = (lane == j) ? d : lij;
     }
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
-      s[c][lane] = a[c];
-      if (lane >= c) Ajj[lane + (int64_t)c * lda] = a[c];
-    }
+    for (int c = 0; c < 64; ++c) s[c][lane] = (c <= lane) ? a[c] : 0.0;
     if (lane == 0 && fail != 0) atomicCAS(info, 0, col0 + fail);
   }
   __syncthreads();
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int r = idx & 63, c = idx >> 6;
+    if (r >= c) Ajj[r + (int64_t)c * lda] = s[c][r];
+  }
   switch (wave) {
     case 0: inv_slice<0>(s, inv, lane); break;
     case 1: inv_slice<1>(s, inv, lane); break;
     case 2: inv_slice<2>(s, inv, lane); break;
-    case 3: inv_slice<3>(s, inv, lane); break;
-    case 4: inv_slice<4>(s, inv, lane); break;
-    case 5: inv_slice<5>(s, inv, lane); break;
-    case 6: inv_slice<6>(s, inv, lane); break;
-    default: inv_slice<7>(s, inv, lane); break;
+    default: inv_slice<3>(s, inv, lane); break;
   }
 }
 
@@ -578,7 +590,7 @@ __global__ __launch_bounds__(256) void copy_strided_kernel(const double* __restr
 
 int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, int64_t ldc,
                    const double* A, int64_t lda, const double* B, int64_t ldb, int64_t m, int64_t n,
-                   int64_t k, int lower) {
+                   int64_t k, int lower, const int* abort_flag, int stagger) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   if ((k % BK) != 0) return bgp_fail(h, -1, "gemm_nt: k=%lld not a multiple of %d", (long long)k, BK);
   if ((m & 1) || (n & 1) || (lda & 1) || (ldb & 1))
@@ -593,13 +605,13 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
   dim3 grid((unsigned)blocks), block(256);
   if (tn == 128 && mode == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj);
+                       (int)k, lower, nti, ntj, abort_flag, stagger);
   else if (tn == 64 && mode == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj);
+                       (int)k, lower, nti, ntj, abort_flag, stagger);
   else if (tn == 64 && mode == 1)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj);
+                       (int)k, lower, nti, ntj, abort_flag, stagger);
   else
     return bgp_fail(h, -1, "gemm_nt: unsupported variant tn=%d mode=%d", tn, mode);
   BGP_HIP(h, hipGetLastError());
@@ -608,7 +620,7 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
 
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv, int* info,
                       int col0, int /*nvalid*/) {
-  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), 0, st, Ajj, lda, inv, info, col0);
+  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }
