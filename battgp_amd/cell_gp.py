@@ -1,0 +1,393 @@
+"""``BatteryCellGP`` - the exact-GP *model object* of the ``full_gp`` path, MI355X-native.
+
+Duck-types what the reference's callers touch on ``gpytorch.models.ExactGP`` as specialised in
+``src/batt_models/cell_gp.py:12-194``:
+
+* zero mean, ``Scale(Wiener[t]) + Scale(ARD-RBF[I, SOC, T])`` + Gaussian noise (``:27-36``);
+* ``train_inputs`` (tuple holding the ``[N, 4]`` tensor), ``train_targets`` (``[N]``) - read by
+  ``BattGP_Full.predict_cell_r0_op`` (``src/batt_models/battgp_full.py:84,98``) and by
+  ``BatteryCellGP_Full.get_training_data`` (``battcellgp_full.py:222-226``);
+* the hyper-parameter / constraint properties (``:64-194``);
+* ``train()`` / ``eval()`` / ``likelihood`` / ``parameters()`` and ``model(x) -> .mean, .variance``
+  (``battcellgp_full.py:171-180``).
+
+Everything numeric happens in libbattgp.so (HIP); torch tensors are containers only.  The engine
+handle is created lazily on first use and freed when the object is deleted - the reference frees
+GPU memory the same way (``del cellmodel.model``, ``battgp_full.py:102-120``).
+
+Differences from the reference, on purpose (findings 6 and 9):
+hyper-parameters are used verbatim in fp64 (the reference rounds them through fp32 raw parameters),
+and the factorisation is always the exact jittered Cholesky (GPyTorch switches to CG/Lanczos above
+N = 800 by default).
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Iterable
+
+import numpy as np
+import torch
+
+from . import KERNEL_BATTGP
+from .engine import ExactGPEngine, as_device_index
+
+MIN_VARIANCE = 1e-10  # gpytorch.settings.min_variance for fp64 (MultivariateNormal.variance)
+
+
+class Constraint:
+    """``gpytorch.constraints.Interval/Positive/GreaterThan/LessThan`` stand-in with the same
+    raw <-> value transforms (sigmoid on intervals, softplus on half-lines); built by
+    :func:`constraint_from_range` exactly as ``src/gpytorch_utils.py:17-33,56-80`` chooses them."""
+
+    def __init__(self, lower, upper):
+        self.lower_bound = np.asarray(lower, dtype=np.float64)
+        self.upper_bound = np.asarray(upper, dtype=np.float64)
+
+    @property
+    def kind(self) -> str:
+        lo_inf = np.all(np.isneginf(self.lower_bound))
+        hi_inf = np.all(np.isposinf(self.upper_bound))
+        if lo_inf and hi_inf:
+            return "free"
+        if hi_inf:
+            return "greater"
+        if lo_inf:
+            return "less"
+        return "interval"
+
+    def transform(self, raw):
+        raw = np.asarray(raw, dtype=np.float64)
+        k = self.kind
+        if k == "free":
+            return raw
+        if k == "greater":
+            return self.lower_bound + np.logaddexp(0.0, raw)
+        if k == "less":
+            return self.upper_bound - np.logaddexp(0.0, -raw)
+        return self.lower_bound + (self.upper_bound - self.lower_bound) / (1.0 + np.exp(-raw))
+
+    def inverse_transform(self, value):
+        value = np.asarray(value, dtype=np.float64)
+        k = self.kind
+        if k == "free":
+            return value
+        if k == "greater":
+            d = value - self.lower_bound
+            return d + np.log(-np.expm1(-d))
+        if k == "less":
+            d = self.upper_bound - value
+            return -(d + np.log(-np.expm1(-d)))
+        p = (value - self.lower_bound) / (self.upper_bound - self.lower_bound)
+        return np.log(p) - np.log1p(-p)
+
+    def dvalue_draw(self, raw):
+        raw = np.asarray(raw, dtype=np.float64)
+        k = self.kind
+        if k == "free":
+            return np.ones_like(raw)
+        sig = 1.0 / (1.0 + np.exp(-raw))
+        if k == "greater":
+            return sig
+        if k == "less":
+            return 1.0 - sig
+        return (self.upper_bound - self.lower_bound) * sig * (1.0 - sig)
+
+    def to(self, _device):
+        return self
+
+    def __repr__(self):
+        return f"Constraint({self.kind}, {self.lower_bound}, {self.upper_bound})"
+
+
+def constraint_from_range(value) -> Constraint:
+    """``(lo, hi)`` or iterable of ``(lo, hi)`` -> :class:`Constraint`
+    (``src/gpytorch_utils.py:17-33`` scalar, ``:56-80`` vector)."""
+    if isinstance(value, Constraint):
+        return value
+    first = value[0]
+    if isinstance(first, (tuple, list, np.ndarray)):
+        lo = [float(v[0]) for v in value]
+        hi = [float(v[1]) for v in value]
+        return Constraint(lo, hi)
+    return Constraint(float(value[0]), float(value[1]))
+
+
+def _as_float_array(values) -> np.ndarray:
+    """``get_tensor`` of the reference (``src/gpytorch_utils.py:36-53``) but in fp64."""
+    if isinstance(values, torch.Tensor):
+        return values.detach().cpu().double().numpy().reshape(-1)
+    if isinstance(values, Iterable):
+        return np.asarray([float(v) for v in values], dtype=np.float64)
+    return np.asarray([float(values)], dtype=np.float64)
+
+
+class _Likelihood:
+    """The slice of ``GaussianLikelihood`` the callers use."""
+
+    def __init__(self, owner: "BatteryCellGP"):
+        self._owner = owner
+        self.training = False
+
+    @property
+    def noise(self) -> torch.Tensor:
+        return torch.tensor([self._owner._noise], dtype=torch.float64)
+
+    @noise.setter
+    def noise(self, value):
+        self._owner._noise = float(_as_float_array(value)[0])
+        self._owner._invalidate()
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, _device):
+        return self
+
+
+class Posterior:
+    """Result of ``model(x)``: ``.mean`` and ``.variance`` as torch tensors, like
+    ``gpytorch.distributions.MultivariateNormal`` (``battcellgp_full.py:173-180``)."""
+
+    def __init__(self, mean: np.ndarray, variance: np.ndarray, device):
+        self.mean = torch.as_tensor(mean, dtype=torch.float64, device=device)
+        self.variance = torch.as_tensor(variance, dtype=torch.float64, device=device)
+
+
+class BatteryCellGP:
+    def __init__(
+        self,
+        train_x: torch.Tensor,
+        train_y: torch.Tensor,
+        *,
+        n_devices: int = 1,
+        output_device=None,
+        device=None,
+        **_kwargs,
+    ):
+        if n_devices < 1:
+            raise ValueError("n_devices must be an integer and >= 1")  # cell_gp.py:47
+        self.n_devices = n_devices
+        self.output_device = output_device
+        x = torch.as_tensor(train_x, dtype=torch.float64)
+        y = torch.as_tensor(train_y, dtype=torch.float64).reshape(-1)
+        if x.ndim != 2 or x.shape[0] != y.shape[0]:
+            raise ValueError("train_x must be [N, D] and train_y [N]")
+        self.device_ = device if device is not None else x.device
+        self.train_inputs = (x.contiguous(),)
+        self.train_targets = y.contiguous()
+        d = x.shape[1]
+        # GPyTorch defaults before the adaptor overwrites them (softplus(0) = ln 2)
+        self._noise = math.log(2.0)
+        self._outputscale_wiener = math.log(2.0)
+        self._outputscale_rbf = math.log(2.0)
+        self._lengthscale_rbf = np.full(d - 1, math.log(2.0))
+        self._c_noise = Constraint(1e-4, np.inf)
+        self._c_sw = Constraint(0.0, np.inf)
+        self._c_sr = Constraint(0.0, np.inf)
+        self._c_ls = Constraint(np.zeros(d - 1), np.full(d - 1, np.inf))
+        self.likelihood = _Likelihood(self)
+        self.training = False
+        self._engine: ExactGPEngine | None = None
+        self._fitted = False
+        self.lml = None
+        self.jitter = None
+
+    # -- module plumbing ------------------------------------------------------------------------
+    def to(self, device):
+        self.device_ = device
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def hyp_vector(self) -> np.ndarray:
+        """``[noise, s_wiener, s_rbf, l_1..l_{D-1}]`` - the C-ABI layout (include/battgp.h)."""
+        return np.concatenate(
+            ([self._noise, self._outputscale_wiener, self._outputscale_rbf], self._lengthscale_rbf)
+        ).astype(np.float64)
+
+    def set_hyp_vector(self, hyp) -> None:
+        hyp = np.asarray(hyp, dtype=np.float64).reshape(-1)
+        self._noise, self._outputscale_wiener, self._outputscale_rbf = (float(v) for v in hyp[:3])
+        self._lengthscale_rbf = hyp[3:].copy()
+        self._invalidate()
+
+    def parameters(self):
+        """Raw (unconstrained) parameters as fp64 tensors, in GPyTorch's registration order
+        (noise, wiener outputscale, rbf outputscale, rbf lengthscale)."""
+        raw = self.raw_vector()
+        return [torch.tensor(raw[0:1]), torch.tensor(raw[1:2]), torch.tensor(raw[2:3]), torch.tensor(raw[3:])]
+
+    def constraints(self):
+        return [self._c_noise, self._c_sw, self._c_sr, self._c_ls]
+
+    def raw_vector(self) -> np.ndarray:
+        return np.concatenate(
+            (
+                np.atleast_1d(self._c_noise.inverse_transform(self._noise)),
+                np.atleast_1d(self._c_sw.inverse_transform(self._outputscale_wiener)),
+                np.atleast_1d(self._c_sr.inverse_transform(self._outputscale_rbf)),
+                np.atleast_1d(self._c_ls.inverse_transform(self._lengthscale_rbf)),
+            )
+        )
+
+    def set_raw_vector(self, raw) -> None:
+        raw = np.asarray(raw, dtype=np.float64).reshape(-1)
+        self._noise = float(self._c_noise.transform(raw[0]))
+        self._outputscale_wiener = float(self._c_sw.transform(raw[1]))
+        self._outputscale_rbf = float(self._c_sr.transform(raw[2]))
+        self._lengthscale_rbf = np.atleast_1d(self._c_ls.transform(raw[3:])).astype(np.float64)
+        self._invalidate()
+
+    def dvalue_draw(self) -> np.ndarray:
+        raw = self.raw_vector()
+        return np.concatenate(
+            (
+                np.atleast_1d(self._c_noise.dvalue_draw(raw[0])),
+                np.atleast_1d(self._c_sw.dvalue_draw(raw[1])),
+                np.atleast_1d(self._c_sr.dvalue_draw(raw[2])),
+                np.atleast_1d(self._c_ls.dvalue_draw(raw[3:])),
+            )
+        )
+
+    # -- engine --------------------------------------------------------------------------------
+    def _invalidate(self):
+        self._fitted = False
+
+    def engine(self) -> ExactGPEngine:
+        if self._engine is None:
+            self._engine = ExactGPEngine(KERNEL_BATTGP, self.hyp_vector(), device=as_device_index(self.device_))
+        return self._engine
+
+    def fit(self) -> float:
+        """Fill + jittered Cholesky + alpha + LML on the GPU (cached until a hyper-parameter
+        changes) - the work GPyTorch does lazily inside the first ``model(x)`` / ``mll`` call."""
+        eng = self.engine()
+        if not self._fitted:
+            x, y = self.train_inputs[0], self.train_targets
+            if eng.n == x.shape[0] and eng.d == x.shape[1] and eng.n > 0:
+                self.lml = eng.refit(self.hyp_vector())  # X, y already resident in HBM
+            else:
+                eng.set_hyp(self.hyp_vector())
+                if x.is_cuda and x.device.index == eng.device_index:
+                    torch.cuda.current_stream(x.device).synchronize()
+                    self.lml = eng.fit_device(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1])
+                else:
+                    self.lml = eng.fit(x.cpu().numpy(), y.cpu().numpy())
+            self.jitter = eng.jitter
+            self._fitted = True
+        return self.lml
+
+    def __call__(self, x) -> Posterior:
+        xq = torch.as_tensor(x, dtype=torch.float64)
+        self.fit()
+        mean, var = self.engine().predict(xq.detach().cpu().numpy(), want_var=True, min_var=MIN_VARIANCE)
+        return Posterior(mean, var, xq.device)
+
+    def posterior_mean(self, x) -> np.ndarray:
+        xq = torch.as_tensor(x, dtype=torch.float64)
+        self.fit()
+        return self.engine().predict(xq.detach().cpu().numpy(), want_var=False)
+
+    def neg_mll(self) -> float:
+        """``-mll`` with ``mll = lml / N`` - the loss of ``src/gp/training.py:29-30,39-40``."""
+        return -self.fit() / self.train_targets.shape[0]
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        self._fitted = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- hyper-parameter properties (cell_gp.py:64-194) -----------------------------------------------
+    @property
+    def noise_variance(self):
+        return self.likelihood.noise
+
+    @noise_variance.setter
+    def noise_variance(self, value):
+        self.likelihood.noise = value
+
+    @property
+    def noise_variance_constraint(self):
+        return self._c_noise
+
+    @noise_variance_constraint.setter
+    def noise_variance_constraint(self, value):
+        self._c_noise = constraint_from_range(value)
+
+    @property
+    def outputscale_wiener(self):
+        return torch.tensor(self._outputscale_wiener, dtype=torch.float64)
+
+    @outputscale_wiener.setter
+    def outputscale_wiener(self, value):
+        self._outputscale_wiener = float(_as_float_array(value)[0])
+        self._invalidate()
+
+    @property
+    def outputscale_wiener_constraint(self):
+        return self._c_sw
+
+    @outputscale_wiener_constraint.setter
+    def outputscale_wiener_constraint(self, value):
+        self._c_sw = constraint_from_range(value)
+
+    @property
+    def outputscale_rbf(self):
+        return torch.tensor(self._outputscale_rbf, dtype=torch.float64)
+
+    @outputscale_rbf.setter
+    def outputscale_rbf(self, value):
+        self._outputscale_rbf = float(_as_float_array(value)[0])
+        self._invalidate()
+
+    @property
+    def outputscale_rbf_constraint(self):
+        return self._c_sr
+
+    @outputscale_rbf_constraint.setter
+    def outputscale_rbf_constraint(self, value):
+        self._c_sr = constraint_from_range(value)
+
+    @property
+    def lengthscale_rbf(self):
+        return torch.tensor(self._lengthscale_rbf, dtype=torch.float64).reshape(1, -1)
+
+    @lengthscale_rbf.setter
+    def lengthscale_rbf(self, value):
+        v = _as_float_array(value)
+        d1 = self.train_inputs[0].shape[1] - 1
+        if v.size == 1:
+            v = np.full(d1, v[0])
+        if v.size != d1:
+            raise ValueError(f"lengthscale_rbf needs {d1} values, got {v.size}")
+        self._lengthscale_rbf = v.astype(np.float64)
+        self._invalidate()
+
+    @property
+    def lengthscale_rbf_constraint(self):
+        return self._c_ls
+
+    @lengthscale_rbf_constraint.setter
+    def lengthscale_rbf_constraint(self, value):
+        # NOTE: in the reference this setter writes to the ScaleKernel instead of the RBF kernel
+        # when n_devices == 1 (cell_gp.py:194 vs the getter :182), so the lengthscale silently
+        # keeps GPyTorch's default Positive() (softplus) constraint.  We reproduce the EFFECTIVE
+        # behaviour: the range is recorded but the transform stays softplus.
+        self._c_ls_requested = constraint_from_range(value)

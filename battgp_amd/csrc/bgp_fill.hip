@@ -1,47 +1,75 @@
 // Covariance fill kernels (gfx950).
 //
-// One workgroup = one 128 x 128 tile of the (column-major) covariance matrix.  The 128
-// column points are scaled once and staged in LDS; every lane keeps two row points in
-// registers and walks 32 columns, so each wave writes one contiguous 1 KiB column segment
-// (16 B per lane) per step: the kernel is a pure coalesced HBM write stream with ~30 fp64
-// VALU ops per entry hidden behind it.  Replaces the >= 6 N^2 passes + N `torch.minimum`
+// One workgroup = one 512 x 32 tile of the (column-major) covariance matrix.  The 32 column
+// points are scaled once and staged in LDS; every lane keeps two row points in registers and
+// the whole workgroup walks the 32 columns together, writing one contiguous 4 KiB column
+// segment (16 B per lane) per step: the kernel is a pure coalesced HBM write stream with ~30
+// fp64 VALU ops per entry hidden behind it.  Replaces the >= 6 N^2 passes + N `torch.minimum`
 // launches of the reference (src/gp/wiener_kernel.py:21-22, RBFKernel/ScaleKernel/AddedDiag
 // at src/batt_models/cell_gp.py:32-36).
 #include "bgp_internal.h"
 
 namespace {
 
-// exp(x) for x <= 0 (finite).  Cody-Waite reduction + degree-13 Taylor/Horner on
-// |r| <= ln2/2 (truncation 4e-18), scaled by v_ldexp_f64 (correct gradual underflow).
-__device__ __forceinline__ double exp_nonpos(double x) {
-  const double L2E = 1.44269504088896338700e+00;
-  const double LN2_HI = 6.93147180369123816490e-01;
-  const double LN2_LO = 1.90821492927058770002e-10;
-  double n = __builtin_rint(x * L2E);
-  double r = __builtin_fma(n, -LN2_HI, x);
-  r = __builtin_fma(n, -LN2_LO, r);
-  double p = 1.6059043836821613e-10;            // 1/13!
-  p = __builtin_fma(p, r, 2.08767569878681e-09);   // 1/12!
-  p = __builtin_fma(p, r, 2.505210838544172e-08);  // 1/11!
-  p = __builtin_fma(p, r, 2.755731922398589e-07);  // 1/10!
-  p = __builtin_fma(p, r, 2.7557319223985893e-06); // 1/9!
-  p = __builtin_fma(p, r, 2.48015873015873e-05);   // 1/8!
-  p = __builtin_fma(p, r, 1.984126984126984e-04);  // 1/7!
-  p = __builtin_fma(p, r, 1.3888888888888889e-03); // 1/6!
-  p = __builtin_fma(p, r, 8.333333333333333e-03);  // 1/5!
-  p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
-  p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
+// 2^(j/64), j = 0..63, correctly rounded (generated with 60-digit decimal arithmetic)
+__device__ const double EXP2_TBL[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951,
+};
+
+// exp(x) for x <= 0 (finite):  x = k ln2/64 + r,  |r| <= ln2/128,  exp(x) = 2^(k>>6) T[k&63] e^r
+// with e^r by a degree-5 Taylor polynomial (truncation r^6/720 <= 3.5e-17) and the scaling by
+// v_ldexp_f64 (correct gradual underflow).  12 fp64 VALU ops + one LDS table read per call -
+// the table-free degree-13 version cost 20 and made the fill VALU-bound at N = 131 072.
+__device__ __forceinline__ double exp_nonpos(double x, const double* __restrict__ tbl) {
+  const double INV = 92.33248261689366;      // 64 / ln2
+  const double L_HI = 0.01083042469326756;  // ln2/64, low 21 bits zero: k * L_HI is exact
+  const double L_LO = 2.9815858269852933e-12;
+  double kd = __builtin_rint(x * INV);
+  double r = __builtin_fma(kd, -L_HI, x);
+  r = __builtin_fma(kd, -L_LO, r);
+  // k >= -2^17 keeps the int conversion and the exact reduction safe for huge |x| (result 0)
+  const int k = (int)__builtin_fmax(kd, -131072.0);
+  const double t = tbl[k & 63];
+  double p = 8.3333333333333332e-03;               // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);  // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);  // 1/3!
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  // n >= -1075 matters only; clamp so the int conversion is safe for huge |x|
-  int ni = (int)__builtin_fmax(n, -2000.0);
-  return __builtin_ldexp(p, ni);
+  return __builtin_ldexp(t * p, k >> 6);
+}
+
+// sqrt(q), q >= 0, to ~1 ulp: v_rsq_f64 seed + one coupled Newton step + residual correction
+// (8 VALU ops; the library sqrt costs ~2x and made the Matern fill VALU-bound)
+__device__ __forceinline__ double sqrt_nonneg(double q) {
+  const double y = __builtin_amdgcn_rsq(q);
+  double r = q * y, h = 0.5 * y;
+  const double e = __builtin_fma(-h, r, 0.5);
+  r = __builtin_fma(r, e, r);
+  h = __builtin_fma(h, e, h);
+  const double d = __builtin_fma(-r, r, q);
+  r = __builtin_fma(d, h, r);
+  return q > 0.0 ? r : 0.0;
 }
 
 template <int KID, int DD>
 __device__ __forceinline__ double kfun(const double (&a)[DD], const double (&b)[DD], int D,
-                                       double s0, double s1) {
+                                       double s0, double s1, const double* __restrict__ tbl) {
   if (KID == BGP_KERNEL_BATTGP) {
     // s_w (m^3/3 + |dt| m^2/2) + s_r exp(-sum_d ((a_d-b_d)/(l_d sqrt2))^2),  d = 1..D-1
     double q = 0.0;
@@ -51,7 +79,7 @@ __device__ __forceinline__ double kfun(const double (&a)[DD], const double (&b)[
         double df = a[d] - b[d];
         q = __builtin_fma(df, df, q);
       }
-    double e = exp_nonpos(-q);
+    double e = exp_nonpos(-q, tbl);
     double m = __builtin_fmin(a[0], b[0]);
     double ad = __builtin_fabs(a[0] - b[0]);
     double m2 = m * m;
@@ -65,8 +93,8 @@ __device__ __forceinline__ double kfun(const double (&a)[DD], const double (&b)[
         double df = a[d] - b[d];
         q = __builtin_fma(df, df, q);
       }
-    double r = __builtin_sqrt(q);  // inputs pre-scaled by sqrt(3)/l: r = sqrt(3) * dist
-    return s0 * (1.0 + r) * exp_nonpos(-r);
+    double r = sqrt_nonneg(q);  // inputs pre-scaled by sqrt(3)/l: r = sqrt(3) * dist
+    return s0 * (1.0 + r) * exp_nonpos(-r, tbl);
   } else {  // SCALED_RBF / ARD_RBF: inputs pre-scaled by 1/(l sqrt2)
     double q = 0.0;
 #pragma unroll
@@ -75,7 +103,7 @@ __device__ __forceinline__ double kfun(const double (&a)[DD], const double (&b)[
         double df = a[d] - b[d];
         q = __builtin_fma(df, df, q);
       }
-    return s0 * exp_nonpos(-q);
+    return s0 * exp_nonpos(-q, tbl);
   }
 }
 
@@ -93,35 +121,59 @@ __device__ __forceinline__ void load_point(const double* __restrict__ x, int64_t
   }
 }
 
-// decode a linear lower-triangular tile index t = ti (ti+1)/2 + tj, tj <= ti
-__device__ __forceinline__ void tri_decode(int64_t t, int& ti, int& tj) {
-  int64_t i = (int64_t)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((i + 1) * (i + 2) / 2 <= t) ++i;
-  while (i * (i + 1) / 2 > t) --i;
-  ti = (int)i;
-  tj = (int)(t - i * (i + 1) / 2);
+// Tile = FT_ROWS x FT_COLS = 512 rows x 32 columns.  All 256 threads of the workgroup work on
+// the SAME column at a time (2 rows each, 16 B per lane): one 4 KiB contiguous store per step,
+// and a workgroup touches only 32 columns - at N = 131 072 a column is 1 MiB, so the old
+// 128-column tile walked 64 different 2 MiB pages per workgroup and the fill ran TLB-bound
+// (3.9 TB/s instead of 5.1 TB/s at N = 40 000).  Tiles are enumerated column-tile-major so that
+// the workgroups resident at any time write the same few columns (same pages, same DRAM rows).
+constexpr int FT_ROWS = 512, FT_COLS = 32, FT_RATIO = FT_ROWS / FT_COLS;
+
+// lower trapezoid: column tile tj needs row tiles ti >= tj / FT_RATIO.  Column tiles are grouped
+// by g = tj / FT_RATIO (each group: FT_RATIO column tiles x (nti - g) row tiles).
+__device__ __forceinline__ bool lower_decode(int64_t t, int nti, int ntj, int& ti, int& tj) {
+  // prefix(g) = FT_RATIO * (g nti - g (g-1) / 2)
+  const double b = 2.0 * nti + 1.0;
+  int64_t g = (int64_t)((b - __builtin_sqrt(b * b - 8.0 * (double)t / FT_RATIO)) * 0.5);
+  if (g < 0) g = 0;
+  auto prefix = [&](int64_t q) { return (int64_t)FT_RATIO * (q * nti - q * (q - 1) / 2); };
+  while (g > 0 && prefix(g) > t) --g;
+  while (prefix(g + 1) <= t) ++g;
+  if (g >= nti) return false;
+  const int64_t r = t - prefix(g);
+  const int64_t rows = nti - g;
+  tj = (int)(g * FT_RATIO + r / rows);
+  ti = (int)(g + r % rows);
+  return tj < ntj;
 }
 
-template <int KID, int DT>
+__host__ int64_t lower_blocks(int nti) {
+  return (int64_t)FT_RATIO * ((int64_t)nti * nti - (int64_t)nti * (nti - 1) / 2);
+}
+
+// ABL != 0: ablation variants for tools/fill_ablate.hip only (1 = no kernel math, 2 = no stores)
+template <int KID, int DT, int ABL = 0>
 __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* __restrict__ x1,
                                                    int64_t n1, const double* __restrict__ x2,
                                                    int64_t n2, double* __restrict__ out, int64_t ld,
                                                    int lower, int add_diag, int64_t nv1, int64_t nv2,
-                                                   int nti, int vec_ok) {
+                                                   int nti, int ntj, int vec_ok) {
   constexpr int DD = DT ? DT : BGP_MAX_DIM;
   const int D = DT ? DT : p.D;
-  __shared__ double sB[128][DD];
+  __shared__ double sB[FT_COLS][DD];
+  __shared__ double sT[64];
+  if (threadIdx.x < 64) sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
 
   int ti, tj;
   if (lower) {
-    tri_decode((int64_t)blockIdx.x, ti, tj);
+    if (!lower_decode((int64_t)blockIdx.x, nti, ntj, ti, tj)) return;
   } else {
     ti = (int)(blockIdx.x % (unsigned)nti);
     tj = (int)(blockIdx.x / (unsigned)nti);
   }
-  const int64_t i0 = (int64_t)ti * 128, j0 = (int64_t)tj * 128;
+  const int64_t i0 = (int64_t)ti * FT_ROWS, j0 = (int64_t)tj * FT_COLS;
 
-  for (int idx = threadIdx.x; idx < 128 * DD; idx += 256) {
+  for (int idx = threadIdx.x; idx < FT_COLS * DD; idx += 256) {
     int c = idx / DD, d = idx % DD;
     int64_t j = j0 + c;
     double v = 0.0;
@@ -132,28 +184,53 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
     sB[c][d] = v;
   }
 
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t i = i0 + 2 * lane;
+  const int64_t i = i0 + 2 * (int64_t)threadIdx.x;
   double a0[DD], a1[DD];
   load_point<KID, DD>(x1, i, nv1, D, p, a0);
   load_point<KID, DD>(x1, i + 1, nv1, D, p, a1);
   __syncthreads();
 
   const double s0 = p.s0, s1 = p.s1, noise = p.noise;
+
+  // Fast path for the vast majority of tiles: completely inside the valid region and off the
+  // diagonal => no predicates, no padding logic, one branch-free basic block of 32 column steps.
+  const bool touches_diag = add_diag && (j0 < i0 + FT_ROWS) && (i0 < j0 + FT_COLS);
+  const bool interior = vec_ok && !touches_diag && (i0 + FT_ROWS <= nv1) && (i0 + FT_ROWS <= n1) &&
+                        (j0 + FT_COLS <= nv2) && (j0 + FT_COLS <= n2);
+  if (interior) {
+    double* dst = out + i + j0 * ld;
+#pragma unroll 8
+    for (int c = 0; c < FT_COLS; ++c) {
+      double b[DD];
+#pragma unroll
+      for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
+      double v0 = (ABL & 1) ? a0[1] + b[1] : kfun<KID, DD>(a0, b, D, s0, s1, sT);
+      double v1 = (ABL & 1) ? a1[1] - b[1] : kfun<KID, DD>(a1, b, D, s0, s1, sT);
+      if (ABL & 2) {
+        if (v0 + v1 == 1.2345e300) out[0] = v0;
+      } else {
+        *reinterpret_cast<double2*>(dst + (int64_t)c * ld) = make_double2(v0, v1);
+      }
+    }
+    return;
+  }
+
   const bool r0_in = i < n1, r1_in = i + 1 < n1;
   const bool r0_val = i < nv1, r1_val = i + 1 < nv1;
 #pragma unroll 4
-  for (int cc = 0; cc < 32; ++cc) {
-    const int c = wave * 32 + cc;
+  for (int c = 0; c < FT_COLS; ++c) {
     const int64_t j = j0 + c;
     if (j >= n2) break;
     double b[DD];
 #pragma unroll
     for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
-    double v0 = kfun<KID, DD>(a0, b, D, s0, s1);
-    double v1 = kfun<KID, DD>(a1, b, D, s0, s1);
+    double v0 = (ABL & 1) ? a0[1] + b[1] : kfun<KID, DD>(a0, b, D, s0, s1, sT);
+    double v1 = (ABL & 1) ? a1[1] - b[1] : kfun<KID, DD>(a1, b, D, s0, s1, sT);
     const bool cval = j < nv2;
+    if (ABL & 2) {  // keep the math alive without the store stream
+      if (v0 + v1 == 1.2345e300) out[0] = v0;
+      continue;
+    }
     if (add_diag) {
       // training fill: + noise on the diagonal; padding rows/cols form an identity block
       if (!(cval && r0_val)) v0 = (i == j) ? 1.0 : 0.0;
@@ -178,18 +255,18 @@ template <int KID>
 int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t n1, const double* x2,
                   int64_t n2, double* out, int64_t ld, int lower, int add_diag, int64_t nv1,
                   int64_t nv2) {
-  const int nti = (int)((n1 + 127) / 128), ntj = (int)((n2 + 127) / 128);
-  int64_t nblocks = lower ? (int64_t)nti * (nti + 1) / 2 : (int64_t)nti * ntj;
+  const int nti = (int)((n1 + FT_ROWS - 1) / FT_ROWS), ntj = (int)((n2 + FT_COLS - 1) / FT_COLS);
+  int64_t nblocks = lower ? lower_blocks(nti) : (int64_t)nti * ntj;
   if (nblocks <= 0) return 0;
   if (nblocks > 0x7fffffffLL) return -1;
   const int vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   dim3 grid((unsigned)nblocks), block(256);
   if (p.D == 4)
     hipLaunchKernelGGL((fill_kernel<KID, 4>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower,
-                       add_diag, nv1, nv2, nti, vec_ok);
+                       add_diag, nv1, nv2, nti, ntj, vec_ok);
   else
     hipLaunchKernelGGL((fill_kernel<KID, 0>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower,
-                       add_diag, nv1, nv2, nti, vec_ok);
+                       add_diag, nv1, nv2, nti, ntj, vec_ok);
   return 0;
 }
 
@@ -202,6 +279,8 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(FillParams p, const double
   const int D = p.D;
   __shared__ double sB[256][DD];
   __shared__ double sV[256];
+  __shared__ double sT[64];
+  if (threadIdx.x < 64) sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double a[DD];
   load_point<KID, DD>(x, i, n, D, p, a);
@@ -221,7 +300,7 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(FillParams p, const double
       double b[DD];
 #pragma unroll
       for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
-      double kv = kfun<KID, DD>(a, b, D, p.s0, p.s1);
+      double kv = kfun<KID, DD>(a, b, D, p.s0, p.s1, sT);
       if (j0 + c == i) kv += diag_add;
       double term = kv * sV[c] - comp;
       double t = acc + term;
@@ -255,9 +334,9 @@ __global__ __launch_bounds__(64) void llt_sample_kernel(FillParams p, const doub
     double a[DD], b[DD];
     load_point<KID, DD>(x, i, n, p.D, p, a);
     load_point<KID, DD>(x, j, n, p.D, p, b);
-    double kij = kfun<KID, DD>(a, b, p.D, p.s0, p.s1) + (i == j ? diag_add : 0.0);
-    double kii = kfun<KID, DD>(a, a, p.D, p.s0, p.s1) + diag_add;
-    double kjj = kfun<KID, DD>(b, b, p.D, p.s0, p.s1) + diag_add;
+    double kij = kfun<KID, DD>(a, b, p.D, p.s0, p.s1, EXP2_TBL) + (i == j ? diag_add : 0.0);
+    double kii = kfun<KID, DD>(a, a, p.D, p.s0, p.s1, EXP2_TBL) + diag_add;
+    double kjj = kfun<KID, DD>(b, b, p.D, p.s0, p.s1, EXP2_TBL) + diag_add;
     out_err[s] = __builtin_fabs(acc - kij) / __builtin_sqrt(kii * kjj);
   }
 }
