@@ -1,0 +1,200 @@
+"""CPU tests: the C-ABI library loads and exports everything include/battgp.h declares; the product
+fails loudly without a GPU; host-side logic of the reference-shaped adaptor."""
+
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from battgp_amd import _lib, synthetic
+from battgp_amd import config as cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "battgp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bgp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"libbattgp.so does not export {name}"
+    assert sorted(_lib.SIGNATURES) == declared, "battgp_amd/_lib.py and include/battgp.h disagree"
+    assert lib.bgp_version() >= 100
+
+
+def test_header_constants_match_python_binding():
+    text = open(os.path.join(ROOT, "include", "battgp.h")).read()
+    for name, val in (("BGP_T_FILL", _lib.T_FILL), ("BGP_T_POTRF", _lib.T_POTRF), ("BGP_T_TRAIL", _lib.T_TRAIL),
+                      ("BGP_T_TRAIL_FLOP", _lib.T_TRAIL_FLOP), ("BGP_T_FILL_BYTES", _lib.T_FILL_BYTES),
+                      ("BGP_T_COUNT", _lib.T_COUNT)):
+        m = re.search(rf"{name}\s*=\s*(\d+)", text)
+        assert m and int(m.group(1)) == val, name
+    import battgp_amd
+
+    for name, val in (("BGP_KERNEL_BATTGP", battgp_amd.KERNEL_BATTGP), ("BGP_KERNEL_SCALED_RBF", battgp_amd.KERNEL_SCALED_RBF),
+                      ("BGP_KERNEL_MATERN32", battgp_amd.KERNEL_MATERN32), ("BGP_KERNEL_ARD_RBF", battgp_amd.KERNEL_ARD_RBF)):
+        m = re.search(rf"{name}\s*=\s*(\d+)", text)
+        assert m and int(m.group(1)) == val, name
+
+
+def _has_gpu():
+    import torch
+
+    return torch.cuda.is_available()
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_fallback():
+    from battgp_amd.engine import EngineError, ExactGPEngine
+
+    with pytest.raises(EngineError, match="no HIP device|bgp_create"):
+        ExactGPEngine(0, synthetic.HYP_BATTGP)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "battgp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_device_argument_forms():
+    import torch
+
+    from battgp_amd.engine import EngineError, as_device_index
+
+    assert as_device_index(None) == 0
+    assert as_device_index(3) == 3
+    assert as_device_index(torch.device("cuda", 2)) == 2
+    assert as_device_index("cuda:5") == 5
+    with pytest.raises(EngineError):
+        as_device_index(torch.device("cpu"))
+
+
+def test_adaptor_construction_is_lazy_and_validates_kwargs():
+    from battgp_amd.battcellgp_full import BatteryCellGP_Full
+
+    x, y = synthetic.make_cell_data(50)
+    cell = BatteryCellGP_Full(x, y, cellnr=3)  # no GPU needed: the engine is created on first use
+    assert cell.cellnr == 3
+    p = cell.get_parameters()
+    assert set(p) == set(BatteryCellGP_Full.get_default_parameters())
+    assert p["noise_variance"] == cfg.NOISE_VARIANCE and p["lengthscale_rbf"] == cfg.LENGTHSCALE_RBF
+    p["max_iter"] = -1  # deep copy: does not leak back
+    assert cell.get_parameters()["max_iter"] == cfg.OPTIM_MAX_ITER
+    xt, yt = cell.get_training_data()
+    assert np.array_equal(xt, x) and np.array_equal(yt, y)
+    assert tuple(cell.model.train_inputs[0].shape) == (50, 4)
+    assert float(cell.model.train_inputs[0][:, 0][0].detach().cpu()) == 0.0  # battgp_full.py:84,98
+    assert np.allclose(cell.model.hyp_vector(), synthetic.HYP_BATTGP, rtol=0, atol=0)
+    with pytest.raises(ValueError, match="unknown keyword parameter 'nois'"):
+        BatteryCellGP_Full(x, y, 1, nois=1.0)
+    cell2 = BatteryCellGP_Full(x, y, 1, noise_variance=1e-3, lengthscale_rbf=(1.0, 2.0, 3.0))
+    assert np.allclose(cell2.model.hyp_vector(), [1e-3, cfg.OUTPUTSCALE_WIENER, cfg.OUTPUTSCALE_RBF, 1, 2, 3])
+    del cell.model  # what BattGP_Full does between cells (battgp_full.py:103,118)
+    assert not hasattr(cell, "model")
+
+
+def test_hyperparameter_csv_layout(tmp_path):
+    import pandas as pd
+
+    from battgp_amd.battcellgp_full import BatteryCellGP_Full
+
+    x, y = synthetic.make_cell_data(20)
+    cell = BatteryCellGP_Full(x, y, cellnr=-1)
+    with pytest.raises(AttributeError):  # like the reference: only set by train_hyperparameters
+        cell.save_hyperparameters(str(tmp_path))
+    cell.marginallikelihood = 12.5
+    cell.save_hyperparameters(str(tmp_path))
+    df = pd.read_csv(tmp_path / "-1hyperparams.csv", index_col=0)
+    assert list(df.index) == ["Noise Variance", "Wiener Outputscale", "RBF Outputscale", "RBF Lengthscale 1",
+                              "RBF Lengthscale 2", "RBF Lengthscale 3", "Marginal Likelihood"]
+    assert float(df.loc["Marginal Likelihood", "params"]) == 12.5
+
+
+def test_constraints_match_gpytorch_transforms():
+    from battgp_amd.cell_gp import Constraint, constraint_from_range
+
+    iv = constraint_from_range((1e-15, 1e4))  # Interval -> sigmoid
+    assert iv.kind == "interval"
+    raw = np.array([-3.0, 0.0, 2.5])
+    val = iv.transform(raw)
+    assert np.allclose(val, 1e-15 + (1e4 - 1e-15) / (1 + np.exp(-raw)))
+    assert np.allclose(iv.inverse_transform(val), raw)
+    pos = constraint_from_range((0.0, math.inf))  # Positive -> softplus
+    assert pos.kind == "greater"
+    assert np.allclose(pos.transform(raw), np.log1p(np.exp(raw)))
+    assert np.allclose(pos.inverse_transform(pos.transform(raw)), raw)
+    vec = constraint_from_range(((1e-5, 1e4), (1e-5, 1e4), (1e-5, 1e4)))
+    assert vec.kind == "interval" and vec.lower_bound.shape == (3,)
+    for c in (iv, pos, Constraint(-math.inf, 5.0)):
+        h = 1e-6
+        fd = (c.transform(raw + h) - c.transform(raw - h)) / (2 * h)
+        assert np.allclose(c.dvalue_draw(raw), fd, rtol=1e-6)
+
+
+def test_raw_vector_round_trip_and_lengthscale_softplus_quirk():
+    from battgp_amd.battcellgp_full import BatteryCellGP_Full
+
+    x, y = synthetic.make_cell_data(10)
+    m = BatteryCellGP_Full(x, y, 1).model
+    raw = m.raw_vector()
+    m.set_raw_vector(raw)
+    assert np.allclose(m.hyp_vector(), synthetic.HYP_BATTGP, rtol=1e-12)
+    # lengthscale keeps GPyTorch's default Positive() transform (reference bug cell_gp.py:194 vs :182)
+    assert np.allclose(np.log1p(np.exp(raw[3:])), cfg.LENGTHSCALE_RBF)
+
+
+def test_training_loops_follow_reference_stop_rule(monkeypatch):
+    """training.train_exact_gp_adam with a stub loss: history length, NaN padding, rel_ftol stop and the
+    final entry (src/gp/training.py:35-65) - no GPU involved."""
+    from battgp_amd import training
+    from battgp_amd.battcellgp_full import BatteryCellGP_Full
+
+    x, y = synthetic.make_cell_data(10)
+    model = BatteryCellGP_Full(x, y, 1).model
+    target = model.raw_vector() + 0.5
+
+    def fake_neg_mll():
+        return 1.0 + float(np.sum((model.raw_vector() - target) ** 2))
+
+    monkeypatch.setattr(model, "neg_mll", fake_neg_mll)
+    losses = training.train_exact_gp_adam(model, max_iter=200, rel_ftol=0.0, loss_scale=10, lr=0.05, messages=False)
+    assert losses.shape == (201,) and not np.isnan(losses).any()
+    assert losses[0] == pytest.approx(10 * (1 + 6 * 0.25))
+    assert losses[-1] < 10.2  # converged towards the minimum value 1.0 * loss_scale
+    model.set_raw_vector(target - 0.5)
+    losses = training.train_exact_gp_adam(model, max_iter=500, rel_ftol=1e-3, loss_scale=1, lr=0.05, messages=False)
+    assert 2 < len(losses) < 500  # stopped by the relative-change rule; array truncated like the reference
+    assert model.training is False and model.likelihood.training is False
+
+
+def test_synthetic_inputs_are_deterministic_and_in_range():
+    x1, y1 = synthetic.make_cell_data(300)
+    x2, y2 = synthetic.make_cell_data(300)
+    assert np.array_equal(x1, x2) and np.array_equal(y1, y2)
+    assert x1[0, 0] == 0.0 and np.all(np.diff(x1[:, 0]) >= 0)
+    assert x1[:, 1].min() >= -80 and x1[:, 1].max() <= -5
+    assert x1[:, 2].min() >= 40 and x1[:, 2].max() <= 95
+    assert x1[:, 3].min() >= 10 and x1[:, 3].max() <= 45
+    q = synthetic.make_query(x1)
+    assert q.shape == (300, 4) and np.all(q[:, 1:] == np.array(synthetic.REF_OP))
+
+
+def test_cells_for_rank_deals_nine_gps_over_eight_gpus():
+    from battgp_amd.parallel import cells_for_rank
+
+    cells = [-1, 1, 2, 3, 4, 5, 6, 7, 8]
+    assert cells_for_rank(cells, 0, 8) == [-1, 8]
+    assert cells_for_rank(cells, 7, 8) == [7]
+    assert sorted(sum((cells_for_rank(cells, r, 8) for r in range(8)), [])) == sorted(cells)

@@ -1,0 +1,182 @@
+"""GPU tests of the reference-shaped surface (BatteryCellGP_Full, ScaledRBFModel, training loops)
+- written to read like the reference's own tests (tests/gp/test_standard_models.py,
+tests/gp/test_spatiotemporal_gp.py:218-282), with the oracle as the checker."""
+
+import gc
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from battgp_amd import config as cfg  # noqa: E402
+from battgp_amd import synthetic, training  # noqa: E402
+from battgp_amd.battcellgp_full import BatteryCellGP_Full, build_cellmodel_full, predict_cells_concurrently  # noqa: E402
+from battgp_amd.operating_point import Op  # noqa: E402
+from battgp_amd.standard_models import ScaledRBFModel  # noqa: E402
+from oracle import kernels as K  # noqa: E402
+from oracle.exact_gp import OracleGP  # noqa: E402
+
+
+class TestStandardModels:
+    """Mirror of the reference's tests/gp/test_standard_models.py:12-47."""
+
+    def test_rbf_1d(self):
+        x = np.array([[1.0]])
+        gp = ScaledRBFModel(torch.Tensor(x), torch.Tensor([10.0]), noise_variance=3.0, outputscale=3.0, lengthscale=2.0)
+        (yq, var_yq) = gp.predict(x)
+        assert yq[0] == pytest.approx(5.0, abs=1e-7)
+        assert var_yq[0] == pytest.approx(1.5, abs=1e-5)
+        gp = ScaledRBFModel(torch.Tensor([[1.0], [1.0]]), torch.Tensor([10.0, 10.0]), noise_variance=3.0, outputscale=3.0, lengthscale=2.0)
+        (yq, var_yq) = gp.predict(x)
+        assert yq[0] == pytest.approx((5.0 / 1.5 + 10.0 / 3.0) / (1 / 1.5 + 1 / 3.0), abs=1e-5)
+        assert var_yq[0] == pytest.approx(3.0 / 3, abs=1e-5)
+
+    def test_noise_free_closed_forms(self):
+        # tests/gp/test_recursive_gp.py:85-102: mean = 10 exp(-d^2/8), var = 3 - 3 exp(-d^2/4)
+        gp = ScaledRBFModel(np.array([[1.0]]), np.array([10.0]), noise_variance=1e-300, outputscale=3.0, lengthscale=2.0)
+        for d in (0.0, 0.5, 1.0, 3.0):
+            m, v = gp.predict(np.array([[1.0 + d]]))
+            assert m[0] == pytest.approx(10.0 * np.exp(-d * d / 8.0), abs=1e-10)
+            assert v[0] == pytest.approx(3.0 - 3.0 * np.exp(-d * d / 4.0), abs=1e-10)
+
+    def test_full_covariance(self):
+        # the exact-GP side of tests/gp/test_recursive_gp.py:195-232 (50 train, 50 query, 3-D)
+        rng = np.random.default_rng(1)
+        xt, yt, xq = rng.uniform(-5, 5, (50, 3)), rng.normal(size=50), rng.uniform(-5, 5, (50, 3))
+        gp = ScaledRBFModel(xt, yt, noise_variance=3.0, outputscale=3.0, lengthscale=2.0)
+        m, c = gp.predict(xq, full_cov=True)
+        ref = OracleGP(K.KERNEL_SCALED_RBF, [3.0, 3.0, 2.0], xt, yt).fit()
+        m_ref, c_ref = ref.predict(xq, full_cov=True)
+        assert np.linalg.norm(m - m_ref) < 1e-9 * np.linalg.norm(m_ref)
+        assert np.linalg.norm(c - c_ref) < 1e-9 * np.linalg.norm(c_ref)
+        assert np.allclose(c, c.T, rtol=0, atol=1e-12)
+
+
+def test_cell_model_matches_oracle_and_reference_output_format():
+    x, y = synthetic.make_cell_data(1200, seed=5)
+    cell = BatteryCellGP_Full(x, y, cellnr=4, device=0)
+    t = np.linspace(x[0, 0], x[-1, 0], 300)
+    op = Op(*synthetic.REF_OP)
+    df = cell.predict_r0_op(op, t)
+    assert list(df.columns) == ["t", "r0_acausal_c4", "r0var_acausal_c4"]
+    xq = np.column_stack((t, np.full(300, op.I), np.full(300, op.SOC), np.full(300, op.T)))
+    ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
+    m_ref, v_ref = ref.predict(xq)  # clamped at 1e-10 like .variance
+    assert np.linalg.norm(df["r0_acausal_c4"] - m_ref) < 1e-6 * np.linalg.norm(m_ref)
+    assert np.max(np.abs(df["r0var_acausal_c4"] - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+    # predict(): tuple / no_cov / full_cov semantics of battcellgp_full.py:168-195
+    m_only = cell.predict(xq, no_cov=True)
+    assert isinstance(m_only, np.ndarray) and np.allclose(m_only, df["r0_acausal_c4"], rtol=1e-12)
+    m, cov = cell.predict(xq[:5], full_cov=True)
+    assert cov.shape == (5, 5) and np.isnan(cov[0, 1]) and np.allclose(np.diag(cov), df["r0var_acausal_c4"][:5])
+    # pack model tag
+    pack = BatteryCellGP_Full(x, y, cellnr=-1, device=torch.device("cuda", 0))
+    assert list(pack.predict_r0_op(op, t[:3]).columns) == ["t", "r0_acausal_pack", "r0var_acausal_pack"]
+    # destroy like BattGP_Full.predict_cell_r0_op does
+    del cell.model
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_model_object_surface_used_by_callers():
+    x, y = synthetic.make_cell_data(300, seed=2)
+    cell = BatteryCellGP_Full(x, y, 1, device=0)
+    mdl = cell.model
+    assert mdl.train_inputs[0].is_cuda and tuple(mdl.train_targets.shape) == (300,)
+    t0 = mdl.train_inputs[0][:, 0]
+    assert float(t0[0].detach().cpu()) == x[0, 0]  # battgp_full.py:84,98
+    out = mdl(torch.tensor(x[:7]))
+    assert out.mean.shape == (7,) and out.variance.shape == (7,) and bool((out.variance >= 1e-10).all())
+    assert float(mdl.noise_variance) == cfg.NOISE_VARIANCE[0]
+    assert tuple(mdl.lengthscale_rbf.detach().cpu().numpy()[0]) == cfg.LENGTHSCALE_RBF
+    assert len(list(mdl.parameters())) == 4
+
+
+class _FakeBattData:
+    """Only the contract build_cellmodel_full needs (src/batt_data/batt_data.py:180-256)."""
+
+    cell_nrs = [1, 2, 3]
+    age = 1200.0
+
+    def generateTrainingData(self, cellnr, max_training_data, max_age):
+        return synthetic.make_cell_data(max_training_data, seed=500 + cellnr)
+
+
+def test_battgp_full_call_sequence():
+    """The call sequence of BattGP_Full (battgp_full.py:41-125) on the plugin: pack + cells, shared 300-point
+    grid from cellmodels[0].model.train_inputs, predict_r0_op each, merge on t, free models."""
+    bd = _FakeBattData()
+    pack = build_cellmodel_full(-1, bd, max_training_data=400, device=0)
+    cells = [build_cellmodel_full(c, bd, max_training_data=400, device=0) for c in bd.cell_nrs]
+    t = cells[0].model.train_inputs[0][:, 0]
+    tt = np.linspace(t[0].detach().cpu(), bd.age, 300)
+    op = Op(*synthetic.REF_OP)
+    df = pack.predict_r0_op(op=op, t=tt)
+    del pack.model
+    for i, c in enumerate(cells):
+        df = df.merge(c.predict_r0_op(op=op, t=tt))
+        if i < len(cells) - 1:
+            del c.model
+    assert df.shape == (300, 1 + 2 * 4)
+    assert {"r0_acausal_pack", "r0_acausal_c1", "r0var_acausal_c3"} <= set(df.columns)
+    assert np.isfinite(df.to_numpy()).all()
+    assert cells[-1].get_training_data()[0].shape == (400, 4)  # plotting.py:233,259 keeps the last model
+
+
+def test_concurrent_models_from_threads():
+    """battgp.py:191-216 drives cells from a thread pool: distinct handles must be independent."""
+    bd = _FakeBattData()
+    cells = [build_cellmodel_full(c, bd, max_training_data=600, device=0) for c in (1, 2, 3)]
+    op = Op(*synthetic.REF_OP)
+    tt = np.linspace(0.0, 1200.0, 100)
+    serial = [c.predict_r0_op(op, tt) for c in cells]
+    for c in cells:
+        c.model._invalidate()
+    out = [None] * 3
+
+    def run(i):
+        out[i] = cells[i].predict_r0_op(op, tt)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for a, b in zip(serial, out):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+    dfs = predict_cells_concurrently(cells, op, tt)
+    for a, b in zip(serial, dfs):
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+
+
+def test_neg_mll_value_is_what_the_reference_reports():
+    x, y = synthetic.make_cell_data(500, seed=11)
+    cell = BatteryCellGP_Full(x, y, 1, device=0)
+    ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
+    n = len(y)
+    assert cell.model.neg_mll() * n == pytest.approx(ref.neg_mll_scaled, rel=1e-6)  # training.py:43 loss*loss_scale
+
+
+def test_train_hyperparameters_decreases_loss_and_updates_params(monkeypatch):
+    x, y = synthetic.make_cell_data(400, seed=21)
+    cell = BatteryCellGP_Full(x, y, 2, device=0, max_iter=15, lr=0.05, rel_tol=0.0,
+                              noise_variance=(1e-5,), outputscale_rbf=0.05)
+    before = cell.get_parameters()
+    losses = cell.train_hyperparameters(messages=False)
+    assert isinstance(losses, np.ndarray) and len(losses) == 16
+    assert losses[-2] < losses[0]
+    after = cell.get_parameters()
+    assert after["noise_variance"] != before["noise_variance"][0]
+    assert isinstance(after["lengthscale_rbf"], tuple) and len(after["lengthscale_rbf"]) == 3
+    assert cell.marginallikelihood == losses[-1]
+    # the model is usable after training and agrees with the oracle at the trained values
+    hyp = cell.model.hyp_vector()
+    xq = synthetic.make_query(x, 20)
+    m = cell.predict(xq, no_cov=True)
+    m_ref, _ = OracleGP(K.KERNEL_BATTGP, hyp, x, y).fit().predict(xq)
+    assert np.linalg.norm(m - m_ref) < 1e-6 * np.linalg.norm(m_ref)
+    monkeypatch.setitem(cfg.HYPER_OPT_PARAMS, "opt_algorithm", "nope")
+    with pytest.raises(ValueError, match="not implemented"):
+        cell.train_hyperparameters(messages=False)
