@@ -61,6 +61,47 @@ def cpu_baseline(kernel_id, hyp, n_cpu: int, m: int, seed: int):
     }
 
 
+def target_size_report(n: int, m: int) -> dict:
+    """One fit+predict per kernel at the size the north-star targets are quoted on (N = 131 072):
+    fill GB/s vs 8 TB/s, trailing-update TFLOP/s vs 78.6, and on-device residuals as correctness
+    evidence where no CPU oracle can follow.  Not part of `value`."""
+    import torch
+
+    from battgp_amd import KERNEL_BATTGP, KERNEL_MATERN32, synthetic
+    from battgp_amd.engine import EngineError, ExactGPEngine
+
+    x, y = synthetic.make_cell_data(n)
+    xq = synthetic.make_query(x, m)
+    rep = {"n": n}
+    for name, kid, hyp in (("battgp", KERNEL_BATTGP, synthetic.HYP_BATTGP), ("matern32", KERNEL_MATERN32, synthetic.HYP_MATERN32)):
+        eng = ExactGPEngine(kid, hyp, device=torch.cuda.current_device())
+        try:
+            t0 = time.perf_counter()
+            eng.fit(x, y)
+            eng.predict(xq)
+            wall = time.perf_counter() - t0
+            ph = eng.phase_times()
+            res = eng.residuals(256)
+            rep[name] = {
+                "fit_predict_s": wall,
+                "fill_gbs": ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9,
+                "fill_frac_hbm": ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "potrf_tflops": (n**3 / 3.0) / (ph["potrf_ms"] * 1e-3) / 1e12,
+                "trail_tflops": ph["trail_flop"] / (ph["trail_ms"] * 1e-3) / 1e12,
+                "trail_frac_mfma": ph["trail_flop"] / (ph["trail_ms"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                "phases_ms": {k: ph[k] for k in ("fill_ms", "potrf_ms", "solve_ms", "cross_ms", "var_ms", "trail_ms")},
+                "lml": eng.lml,
+                "jitter": eng.jitter,
+                "residuals": {"rel_solve": res[0], "max_llt": res[1]},
+                "device_bytes": eng.device_bytes(),
+            }
+        except EngineError as exc:  # e.g. not enough HBM on a smaller part
+            rep[name] = {"error": str(exc)}
+        finally:
+            eng.close()
+    return rep
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +113,8 @@ def main() -> None:
     ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
     ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
+    ap.add_argument("--target-n", type=int, default=131072,
+                    help="also report the kernels' roofline fractions at the north-star size (1 GPU only; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -79,19 +122,15 @@ def main() -> None:
     from battgp_amd import KERNEL_BATTGP, KERNEL_MATERN32, synthetic
     from battgp_amd.engine import ExactGPEngine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from battgp_amd import parallel
+
+    rank, world, local_rank = parallel.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(
             f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
         )
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist = parallel.init("nccl", device=torch.device("cuda", local_rank))  # RCCL; None for 1 process
 
     kernel_id, hyp = (
         (KERNEL_BATTGP, synthetic.HYP_BATTGP) if args.kernel == "battgp" else (KERNEL_MATERN32, synthetic.HYP_MATERN32)
@@ -117,8 +156,7 @@ def main() -> None:
         eng.predict_device(txq.data_ptr(), m, tmean.data_ptr(), tvar.data_ptr(), 1e-10)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        parallel.barrier(dist)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -131,10 +169,7 @@ def main() -> None:
         phases.append(eng.phase_times())
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(dist, elapsed, device=dev)
 
     resid = None
     if not args.no_residuals:
@@ -202,6 +237,9 @@ def main() -> None:
             "mean_first": [float(v) for v in mean_host[:3]],
             "device_bytes": mem_bytes,
         }
+        out["roofline"]["launches_per_step"] = int(2 * max(0, -(-(((n + 63) // 64) * 64) // (args.nb if args.nb > 0 else 512)) - 1))
+        if world == 1 and args.target_n > 0 and args.target_n != n:
+            out["target_size"] = target_size_report(args.target_n, m)
         if args.cpu_n > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(kernel_id, hyp, args.cpu_n, m, seed=args.cpu_n)
         elif world > 1:
