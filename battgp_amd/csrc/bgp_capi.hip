@@ -124,13 +124,13 @@ struct PhaseTimer {
 //      st:          [wait panel(0)] rest(0) [wait panel(1)] rest(1) ...
 //  Every element still receives exactly the same single rank-NB update, so the factor is
 //  bit-identical with and without look-ahead.
-int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t lda, double* inv, int* dinfo,
+int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t nrows, int64_t lda, double* inv, int* dinfo,
                  int64_t K0, int64_t nbk) {
   for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
     double* inv_j = inv + (j / BGP_IB) * (BGP_IB * BGP_IB);
     int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)j, 64);
     if (rc) return rc;
-    const int64_t rows_below = n - (j + BGP_IB);
+    const int64_t rows_below = nrows - (j + BGP_IB);
     if (rows_below > 0) {
       double* A21 = A + (j + BGP_IB) + j * lda;
       rc = launch_gemm_nt(h, st, 1, 64, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0, dinfo);
@@ -202,9 +202,13 @@ int check_info(bgp_handle* h, hipStream_t st, hipStream_t sp, int* dinfo, int* o
   return 0;
 }
 
-int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t lda, double* inv, int* dinfo,
-                 int* info_out, bool time_trailing) {
+// `nrows >= n`: rows n..nrows-1 are extra rows BELOW the square matrix (the augmented block whose
+// row n carries y^T): they ride through every TRSM / update like any other row below the
+// diagonal and come out as (L^-1 y)^T - the forward solve costs no launch of its own.
+int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t nrows, int64_t lda, double* inv,
+                 int* dinfo, int* info_out, bool time_trailing) {
   const int64_t NB = h->nb_outer;
+  const int64_t extra = nrows - n;
   const bool la = h->lookahead != 0 && n > 2 * NB;
   hipStream_t sp = la ? h->s_aux : st;
   BGP_HIP(h, hipMemsetAsync(dinfo, 0, sizeof(int), st));
@@ -222,12 +226,12 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t ld
     const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
     const int64_t K1 = K0 + nbk;
     const int64_t rows_trail = n - K1;
-    if ((rc = factor_panel(h, sp, A, n, lda, inv, dinfo, K0, nbk))) return rc;
+    if ((rc = factor_panel(h, sp, A, nrows, lda, inv, dinfo, K0, nbk))) return rc;
     if (rows_trail > 0) {
       double* P = A + K1 + K0 * lda;
       if (!la) {
         if ((rc = tt.begin(st))) return rc;
-        rc = launch_gemm_nt(h, st, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail, rows_trail, nbk, 1, dinfo);
+        rc = launch_gemm_nt(h, st, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail + extra, rows_trail, nbk, 1, dinfo);
         if (rc) return rc;
         if ((rc = tt.end(st, (double)rows_trail, (double)rows_trail, (double)nbk, true))) return rc;
       } else {
@@ -240,7 +244,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t ld
         // la(k) on sp rewrites columns that rest(k-1) also updated: order it after rest(k-1)
         if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + 2 * (size_t)(step - 1)], 0));
         if ((rc = tt.begin(sp))) return rc;
-        rc = launch_gemm_nt(h, sp, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail, nbn, nbk, 1, dinfo);
+        rc = launch_gemm_nt(h, sp, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail + extra, nbn, nbk, 1, dinfo);
         if (rc) return rc;
         if ((rc = tt.end(sp, (double)rows_trail, (double)nbn, (double)nbk, false))) return rc;
         // rest(k) on st: everything right of the next panel
@@ -252,8 +256,8 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t ld
           const int64_t nt_rest = (rows_rest + 127) / 128;
           const int64_t rounds = nt_rest * (nt_rest + 1) / 2 / 512;
           const int stagger = (rounds >= 8) ? (int)((nbk / 16) * 3.6 / 8.0 / 1.7 + 1.0) : 0;
-          rc = launch_gemm_nt(h, st, 0, 128, A + K2 + K2 * lda, lda, P2, lda, P2, lda, rows_rest, rows_rest, nbk, 1,
-                              dinfo, stagger);
+          rc = launch_gemm_nt(h, st, 0, 128, A + K2 + K2 * lda, lda, P2, lda, P2, lda, rows_rest + extra, rows_rest, nbk,
+                              1, dinfo, stagger);
           if (rc) return rc;
           if ((rc = tt.end(st, (double)rows_rest, (double)rows_rest, (double)nbk, true))) return rc;
         }
@@ -308,23 +312,6 @@ int ensure_part(bgp_handle* h, int64_t need) {
   return 0;
 }
 
-// z = L^-1 y : dz holds y (zero padded) on entry and z on exit
-int forward_driver(bgp_handle* h, hipStream_t st) {
-  const int64_t n = h->Npad, lda = h->lda, NB = h->nb_outer;
-  for (int64_t K0 = 0; K0 < n; K0 += NB) {
-    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
-    const int64_t K1 = K0 + nbk;
-    int rc = launch_trsv_block_fwd(h, st, h->dA + K0 + K0 * lda, lda, h->dInv + (K0 / BGP_IB) * (BGP_IB * BGP_IB),
-                                   h->dz + K0, (int)nbk);
-    if (rc) return rc;
-    if (n - K1 > 0) {
-      rc = launch_gemv_n_sub(h, st, h->dA + K1 + K0 * lda, lda, h->dz + K0, (int)nbk, h->dz + K1, n - K1);
-      if (rc) return rc;
-    }
-  }
-  return 0;
-}
-
 // alpha = L^-T z
 int backward_driver(bgp_handle* h, hipStream_t st) {
   const int64_t n = h->Npad, lda = h->lda, NB = h->nb_outer;
@@ -366,8 +353,10 @@ int alloc_problem(bgp_handle* h, int64_t N, int D) {
   free_problem(h);
   const int64_t Npad = round_up(N, BGP_IB);
   // column stride: avoid large power-of-two strides (all columns of a tile in one HBM channel)
-  int64_t lda = Npad;
-  if (Npad >= 2048 && (Npad % 512) == 0) lda += 64;
+  // + 64 rows for the augmented block (row Npad = y^T); avoid large power-of-two column strides
+  // (all columns of a tile in one HBM channel)
+  int64_t lda = Npad + BGP_AUG;
+  if (lda >= 2048 && (lda % 512) == 0) lda += 64;
   h->N = N;
   h->D = D;
   h->Npad = Npad;
@@ -401,11 +390,12 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out) {
       PhaseTimer t(h, st, BGP_T_FILL, true);
       rc = launch_fill(h, st, p, h->dX, Npad, h->dX, Npad, h->dA, lda, 1, 1, N, N);
       if (rc) return rc;
+      if ((rc = launch_aug_rows(h, st, h->dy, N, h->dA + Npad, lda, Npad, BGP_AUG))) return rc;
       if ((rc = t.stop())) return rc;
     }
     {
       PhaseTimer t(h, st, BGP_T_POTRF, true);
-      rc = potrf_driver(h, st, h->dA, Npad, lda, h->dInv, h->dinfo, &info, true);
+      rc = potrf_driver(h, st, h->dA, Npad, Npad + BGP_AUG, lda, h->dInv, h->dinfo, &info, true);
       if (rc) return rc;
       if ((rc = t.stop())) return rc;
     }
@@ -422,9 +412,9 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out) {
   {
     PhaseTimer t(h, st, BGP_T_SOLVE);
     int rc;
-    if ((rc = launch_copy_strided(h, st, h->dy, N, h->dz, 1, Npad))) return rc;
-    if ((rc = forward_driver(h, st))) return rc;
-    if ((rc = backward_driver(h, st))) return rc;
+    // z^T = row Npad of the factor (came out of the factorisation); alpha = L^-T z is computed
+    // lazily (ensure_alpha) - the predictive path with variance never needs it
+    if ((rc = launch_gather_row(h, st, h->dA + Npad, lda, Npad, h->dz))) return rc;
     if ((rc = launch_fit_scalars(h, st, h->dA, lda, h->dz, 1, Npad, h->dscal))) return rc;
     BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     if ((rc = t.stop())) return rc;
@@ -432,8 +422,19 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out) {
   const double logdet_half = h->hscal[0], zz = h->hscal[1];
   h->lml = -0.5 * zz - logdet_half - 0.5 * (double)N * log(2.0 * M_PI);
   h->fitted = true;
+  h->alpha_ready = false;
   if (lml_out) *lml_out = h->lml;
   if (jitter_out) *jitter_out = h->jitter_used;
+  return 0;
+}
+
+int ensure_alpha(bgp_handle* h) {
+  if (h->alpha_ready) return 0;
+  PhaseTimer t(h, h->s_main, BGP_T_SOLVE);
+  int rc = backward_driver(h, h->s_main);
+  if (rc) return rc;
+  if ((rc = t.stop())) return rc;
+  h->alpha_ready = true;
   return 0;
 }
 
@@ -470,19 +471,31 @@ int predict_resident(bgp_handle* h, int64_t M, bool want_var, double min_var) {
   FillParams p;
   int rc = make_fill_params(h, h->D, 0.0, &p);
   if (rc) return rc;
-  {
+  if (!want_var) {
+    // mean only (the `no_cov` path): cross fill + K_*X alpha, no triangular solve of the query block
+    if ((rc = ensure_alpha(h))) return rc;
     PhaseTimer t(h, st, BGP_T_CROSS);
     if ((rc = launch_fill(h, st, p, h->dXq, Mpad, h->dX, Npad, h->dE, lde, 0, 0, M, h->N))) return rc;
     int nch = 0;
     if ((rc = launch_rowdot(h, st, h->dE, lde, M, Npad, h->dalpha, h->dpart, &nch))) return rc;
     if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, nullptr, &p, -1.0, h->dout))) return rc;
     if ((rc = t.stop())) return rc;
+    h->times[BGP_T_VAR] = 0.0;
+    return 0;
   }
-  h->times[BGP_T_VAR] = 0.0;
-  if (want_var) {
+  {
+    PhaseTimer t(h, st, BGP_T_CROSS);
+    if ((rc = launch_fill(h, st, p, h->dXq, Mpad, h->dX, Npad, h->dE, lde, 0, 0, M, h->N))) return rc;
+    if ((rc = t.stop())) return rc;
+  }
+  {
+    // V^T = K_*X L^-T, then  mean = V^T z  (= K_*X alpha without the backward solve) and
+    // var = k_** - rowsumsq(V^T)
     PhaseTimer t(h, st, BGP_T_VAR);
     if ((rc = epass_driver(h, st, h->dE, lde, Mpad, h->dA, Npad, h->lda, h->dInv))) return rc;
     int nch = 0;
+    if ((rc = launch_rowdot(h, st, h->dE, lde, M, Npad, h->dz, h->dpart, &nch))) return rc;
+    if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, nullptr, &p, -1.0, h->dout))) return rc;
     if ((rc = launch_rowdot(h, st, h->dE, lde, M, Npad, nullptr, h->dpart, &nch))) return rc;
     if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, h->dXq, &p, min_var, h->dout + M))) return rc;
     if ((rc = t.stop())) return rc;
@@ -727,6 +740,7 @@ int bgp_get_alpha(bgp_handle* h, double* alpha_host) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!h->fitted || !alpha_host) return bgp_fail(h, -1, "bgp_get_alpha: no fit / NULL output");
+  if ((rc = ensure_alpha(h))) return rc;
   BGP_HIP(h, hipMemcpyAsync(alpha_host, h->dalpha, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->s_main));
   BGP_HIP(h, hipStreamSynchronize(h->s_main));
   return 0;
@@ -736,6 +750,7 @@ int bgp_residuals(bgp_handle* h, int nsample, double* out2) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!h->fitted || !out2) return bgp_fail(h, -1, "bgp_residuals: no fit / NULL output");
+  if ((rc = ensure_alpha(h))) return rc;
   if (nsample < 2) nsample = 2;
   if (nsample > 65536) nsample = 65536;
   hipStream_t st = h->s_main;
@@ -779,7 +794,7 @@ int bgp_potrf_dev(bgp_handle* h, double* A_dev, int64_t n, int64_t lda, int* inf
   int info = 0;
   {
     PhaseTimer t(h, h->s_main, BGP_T_POTRF);
-    rc = potrf_driver(h, h->s_main, A_dev, n, lda, inv, h->dinfo, &info, true);
+    rc = potrf_driver(h, h->s_main, A_dev, n, n, lda, inv, h->dinfo, &info, true);
     if (!rc) rc = t.stop();
   }
   dev_free(h, &inv, n * BGP_IB);

@@ -10,6 +10,7 @@
 #include "../../include/battgp.h"
 
 #define BGP_IB 64  // inner (diagonal tile) block of the Cholesky; also the K-granule of the path
+#define BGP_AUG 64 // rows of the augmented block below the matrix (row 0 of it carries y^T)
 
 struct FillParams {
   int kid;         // BGP_KERNEL_*
@@ -39,6 +40,7 @@ struct bgp_handle {
   int64_t N = 0, Npad = 0, lda = 0;
   int D = 0;
   bool fitted = false;
+  bool alpha_ready = false;
   double jitter_used = 0.0, lml = 0.0;
   // device buffers
   double* dX = nullptr;      // [N, D] row-major
@@ -86,10 +88,9 @@ int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, d
                       int* info, int col0, int nvalid);
 int launch_fit_scalars(bgp_handle* h, hipStream_t st, const double* A, int64_t lda, const double* z,
                        int64_t ldz, int64_t n, double* out2);
-int launch_trsv_block_fwd(bgp_handle* h, hipStream_t st, const double* Lkk, int64_t lda, const double* invK,
-                          double* w, int nbk);
-int launch_gemv_n_sub(bgp_handle* h, hipStream_t st, const double* P, int64_t lda, const double* z, int nbk,
-                      double* y, int64_t rows);
+int launch_aug_rows(bgp_handle* h, hipStream_t st, const double* y, int64_t n, double* Aaug, int64_t lda,
+                    int64_t ncols, int naug);  // Aaug[r + j*lda] = (r == 0 && j < n) ? y[j] : 0
+int launch_gather_row(bgp_handle* h, hipStream_t st, const double* row, int64_t ld, int64_t n, double* dst);
 int launch_gemv_t_partial(bgp_handle* h, hipStream_t st, const double* P, int64_t lda, const double* x,
                           int64_t rows, int nbk, double* part, int* nchunks_out);
 int launch_trsv_block_bwd(bgp_handle* h, hipStream_t st, const double* Lkk, int64_t lda, const double* invK,

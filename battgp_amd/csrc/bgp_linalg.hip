@@ -374,71 +374,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// in place: w[0..nbk) <- L_KK^-1 w.   One workgroup of 512 threads.
-__global__ __launch_bounds__(512) void trsv_block_fwd_kernel(const double* __restrict__ Lkk, int64_t lda,
-                                                             const double* __restrict__ invK,
-                                                             double* __restrict__ w, int nbk) {
-  __shared__ double sw[TRSV_MAX_NB];
-  __shared__ double sp[8][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < nbk; i += 512) sw[i] = w[i];
-  __syncthreads();
-  for (int j = 0; j < nbk; j += 64) {
-    // z_j = inv_j * w_j : wave q sums columns [8q, 8q+8) for all 64 rows (lane = row, coalesced)
-    const double* inv_j = invK + (int64_t)(j / 64) * 4096;
-    {
-      double acc = 0.0;
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        const int c = wave * 8 + cc;
-        acc = __builtin_fma(inv_j[lane + c * 64], sw[j + c], acc);
-      }
-      sp[wave][lane] = acc;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      double z = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) z += sp[q][tid];
-      sw[j + tid] = z;
-    }
-    __syncthreads();
-    // rows below inside the block: w_i -= sum_c L(i, j+c) z_c
-    for (int i = j + 64 + tid; i < nbk; i += 512) {
-      double acc = 0.0;
-      const double* Lrow = Lkk + i + (int64_t)j * lda;
-#pragma unroll 8
-      for (int c = 0; c < 64; ++c) acc = __builtin_fma(Lrow[(int64_t)c * lda], sw[j + c], acc);
-      sw[i] -= acc;
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < nbk; i += 512) w[i] = sw[i];
-}
-
-// y[r] -= sum_{c<nbk} P[r, c] z[c]  for r < rows.  Workgroup = 64 rows x 4 column quarters.
-__global__ __launch_bounds__(256) void gemv_n_sub_kernel(const double* __restrict__ P, int64_t lda,
-                                                         const double* __restrict__ z, int nbk,
-                                                         double* __restrict__ y, int64_t rows) {
-  __shared__ double sz[TRSV_MAX_NB];
-  __shared__ double sp[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < nbk; i += 256) sz[i] = z[i];
-  __syncthreads();
-  const int64_t r = (int64_t)blockIdx.x * 64 + lane;
-  const int cq = nbk / 4;  // nbk is a multiple of 64
-  double acc = 0.0;
-  if (r < rows) {
-    const double* Pr = P + r + (int64_t)(wave * cq) * lda;
-    const double* zz = sz + wave * cq;
-#pragma unroll 8
-    for (int c = 0; c < cq; ++c) acc = __builtin_fma(Pr[(int64_t)c * lda], zz[c], acc);
-  }
-  sp[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0 && r < rows) y[r] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
-}
-
 // part[chunk * nbk + c] = sum_{r in chunk} P[r, c] x[r];  grid = (row chunks of 1024, nbk / 64)
 constexpr int GT_ROWS = 1024;
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* __restrict__ P, int64_t lda,
@@ -579,6 +514,22 @@ __global__ __launch_bounds__(1024) void norm2_kernel(const double* __restrict__ 
   if (threadIdx.x == 0) out[0] = r0[0];
 }
 
+// augmented block below the matrix: row 0 = y^T (zero in the padding), other rows zero
+__global__ __launch_bounds__(256) void aug_rows_kernel(const double* __restrict__ y, int64_t n,
+                                                       double* __restrict__ Aaug, int64_t lda, int64_t ncols,
+                                                       int naug) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = idx / naug;
+  const int r = (int)(idx % naug);
+  if (j < ncols) Aaug[r + j * lda] = (r == 0 && j < n) ? y[j] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void gather_row_kernel(const double* __restrict__ row, int64_t ld, int64_t n,
+                                                         double* __restrict__ dst) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) dst[j] = row[j * ld];
+}
+
 __global__ __launch_bounds__(256) void copy_strided_kernel(const double* __restrict__ src, int64_t n,
                                                            double* __restrict__ dst, int64_t ld,
                                                            int64_t npad) {
@@ -632,23 +583,6 @@ int launch_fit_scalars(bgp_handle* h, hipStream_t st, const double* A, int64_t l
   return 0;
 }
 
-int launch_trsv_block_fwd(bgp_handle* h, hipStream_t st, const double* Lkk, int64_t lda, const double* invK,
-                          double* w, int nbk) {
-  if (nbk > TRSV_MAX_NB) return bgp_fail(h, -1, "nb_outer=%d exceeds the TRSV limit %d", nbk, TRSV_MAX_NB);
-  hipLaunchKernelGGL(trsv_block_fwd_kernel, dim3(1), dim3(512), 0, st, Lkk, lda, invK, w, nbk);
-  BGP_HIP(h, hipGetLastError());
-  return 0;
-}
-
-int launch_gemv_n_sub(bgp_handle* h, hipStream_t st, const double* P, int64_t lda, const double* z, int nbk,
-                      double* y, int64_t rows) {
-  if (rows <= 0) return 0;
-  hipLaunchKernelGGL(gemv_n_sub_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st, P, lda, z, nbk, y,
-                     rows);
-  BGP_HIP(h, hipGetLastError());
-  return 0;
-}
-
 int launch_gemv_t_partial(bgp_handle* h, hipStream_t st, const double* P, int64_t lda, const double* x,
                           int64_t rows, int nbk, double* part, int* nchunks_out) {
   const int nch = (int)((rows + GT_ROWS - 1) / GT_ROWS);
@@ -690,6 +624,21 @@ int launch_rowdot_finish(bgp_handle* h, hipStream_t st, const double* part, int 
 
 int launch_norm2(bgp_handle* h, hipStream_t st, const double* a, const double* b, int64_t n, double* out) {
   hipLaunchKernelGGL(norm2_kernel, dim3(1), dim3(1024), 0, st, a, b, n, out);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_aug_rows(bgp_handle* h, hipStream_t st, const double* y, int64_t n, double* Aaug, int64_t lda,
+                    int64_t ncols, int naug) {
+  const int64_t total = ncols * naug;
+  hipLaunchKernelGGL(aug_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, n, Aaug, lda, ncols,
+                     naug);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_gather_row(bgp_handle* h, hipStream_t st, const double* row, int64_t ld, int64_t n, double* dst) {
+  hipLaunchKernelGGL(gather_row_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, row, ld, n, dst);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

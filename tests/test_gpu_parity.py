@@ -145,7 +145,7 @@ def _check_case(kid, hyp, x, y, xq, rel=REL):
     assert e.jitter == gp.jitter == 0.0
     assert abs(lml - gp.lml) <= rel * abs(gp.lml), (lml, gp.lml)
     assert rel_err(m, m_ref) < rel
-    assert np.array_equal(m, m_only)
+    assert rel_err(m_only, m) < 1e-9  # mean-only path uses K_*X alpha, the variance path V^T z
     assert rel_err(alpha, gp.alpha) < 1e-4  # alpha is cond-amplified; the mean is the contract
     # variance: a catastrophic-cancellation quantity - compare against the prior scale
     kdiag = K.kernel_diag(kid, hyp, xq)
