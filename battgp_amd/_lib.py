@@ -44,6 +44,23 @@ SIGNATURES = {
         C.c_int,
         [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_double],
     ),
+    "bgp_fill_block_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_double],
+    ),
+    "bgp_aug_rows_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]),
+    "bgp_factor_panel_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, c_int_p]),
+    "bgp_solve_panel_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p],
+    ),
+    "bgp_gemm_nt_sub_async_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int],
+    ),
+    "bgp_diag_logsum_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
+    "bgp_rowdot_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bgp_sync": (C.c_int, [handle_p]),
 }
 
 # indices of bgp_phase_times (BGP_T_* in battgp.h)

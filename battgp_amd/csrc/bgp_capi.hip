@@ -829,4 +829,86 @@ int bgp_fill_dev(bgp_handle* h, const double* x1_dev, int64_t n1, const double* 
   return rc;
 }
 
+int bgp_fill_block_dev(bgp_handle* h, const double* X_dev, int64_t N, int D, int64_t row0, int64_t col0,
+                       int64_t nrows, int64_t ncols, double* out_dev, int64_t ld, double extra_diag) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  FillParams p;
+  if ((rc = make_fill_params(h, D, extra_diag, &p))) return rc;
+  if (row0 < 0 || col0 < 0 || nrows < 1 || ncols < 1) return bgp_fail(h, -1, "bgp_fill_block_dev: bad block");
+  const int64_t nv1 = N > row0 ? N - row0 : 0, nv2 = N > col0 ? N - col0 : 0;
+  // x pointers are only dereferenced for indices < nvalid, so offsets past N are never read
+  return launch_fill(h, h->s_main, p, X_dev + row0 * D, nrows, X_dev + col0 * D, ncols, out_dev, ld, 0,
+                     row0 == col0 ? 1 : 0, nv1, nv2);
+}
+
+int bgp_aug_rows_dev(bgp_handle* h, const double* y_dev, int64_t N, int64_t col0, int64_t ncols, double* aug_dev,
+                     int64_t ld) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const int64_t nv = N > col0 ? N - col0 : 0;
+  return launch_aug_rows(h, h->s_main, y_dev + col0, nv, aug_dev, ld, ncols, BGP_AUG);
+}
+
+int bgp_factor_panel_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t nrows, int nbk, double* inv_dev,
+                         int* info_out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!panel_dev || !inv_dev || nbk < 64 || (nbk % 64) != 0 || nrows < nbk || (nrows & 1) || (ld & 1))
+    return bgp_fail(h, -1, "bgp_factor_panel_dev: bad arguments (nrows=%lld nbk=%d ld=%lld)", (long long)nrows, nbk,
+                    (long long)ld);
+  BGP_HIP(h, hipMemsetAsync(h->dinfo, 0, sizeof(int), h->s_main));
+  if ((rc = factor_panel(h, h->s_main, panel_dev, nrows, ld, inv_dev, h->dinfo, 0, nbk))) return rc;
+  int info = 0;
+  if ((rc = check_info(h, h->s_main, nullptr, h->dinfo, &info))) return rc;
+  if (info_out) *info_out = info;
+  return 0;
+}
+
+int bgp_solve_panel_dev(bgp_handle* h, double* E_dev, int64_t lde, int64_t me, const double* Lkk_dev, int64_t ld,
+                        int nbk, const double* inv_dev) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (nbk > h->nb_outer) return bgp_fail(h, -1, "bgp_solve_panel_dev: nbk=%d exceeds nb_outer=%d", nbk, h->nb_outer);
+  return epass_driver(h, h->s_main, E_dev, lde, me, Lkk_dev, nbk, ld, inv_dev);
+}
+
+int bgp_gemm_nt_sub_async_dev(bgp_handle* h, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                              const double* B_dev, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  return launch_gemm_nt(h, h->s_main, 0, 128, C_dev, ldc, A_dev, lda, B_dev, ldb, m, n, k, lower);
+}
+
+int bgp_diag_logsum_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t n, double* out_host) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  // fit_scalars sums log of the diagonal and the squares of a vector: reuse with z = the diagonal itself
+  if ((rc = launch_fit_scalars(h, h->s_main, A_dev, ld, A_dev, ld + 1, n, h->dscal + 4))) return rc;
+  BGP_HIP(h, hipMemcpyAsync(h->hscal + 4, h->dscal + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, h->s_main));
+  BGP_HIP(h, hipStreamSynchronize(h->s_main));
+  if (out_host) *out_host = h->hscal[4];
+  return 0;
+}
+
+int bgp_rowdot_dev(bgp_handle* h, const double* E_dev, int64_t lde, int64_t M, int64_t n, const double* vec_dev,
+                   double* out_dev) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if ((rc = ensure_part(h, ((n + 511) / 512 + 1) * M))) return rc;
+  int nch = 0;
+  if ((rc = launch_rowdot(h, h->s_main, E_dev, lde, M, n, vec_dev, h->dpart, &nch))) return rc;
+  FillParams p;
+  memset(&p, 0, sizeof(p));
+  return launch_rowdot_finish(h, h->s_main, h->dpart, nch, M, nullptr, &p, -1.0, out_dev);
+}
+
+int bgp_sync(bgp_handle* h) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  BGP_HIP(h, hipStreamSynchronize(h->s_main));
+  BGP_HIP(h, hipStreamSynchronize(h->s_aux));
+  return 0;
+}
+
 }  // extern "C"

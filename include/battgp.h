@@ -159,6 +159,48 @@ int bgp_gemm_nt_sub_dev(bgp_handle* h, double* C_dev, int64_t ldc, const double*
 int bgp_fill_dev(bgp_handle* h, const double* x1_dev, int64_t n1, const double* x2_dev,
                  int64_t n2, int D, double* out_dev, int64_t ld, int lower, double diag_add);
 
+
+/* ---- building blocks of the sharded (column-panel block-cyclic) Cholesky: one process per GPU,
+ * panels broadcast over RCCL by the host driver (battgp_amd/sharded.py).  A rank stores whole
+ * column panels: all rows from the panel's diagonal down, plus the augmented block.  These calls
+ * are ASYNCHRONOUS on the handle's stream unless stated; bgp_sync() drains it. ---- */
+
+/* out[(i-row0) + (j-col0)*ld] = Sigma_ij = K(x_i, x_j) + (noise + extra_diag) [i == j] for
+ * i in [row0, row0+nrows), j in [col0, col0+ncols); indices >= N are padding (identity).
+ * The diagonal term is applied only when row0 == col0 (a panel that starts on the diagonal). */
+int bgp_fill_block_dev(bgp_handle* h, const double* X_dev, int64_t N, int D, int64_t row0, int64_t col0,
+                       int64_t nrows, int64_t ncols, double* out_dev, int64_t ld, double extra_diag);
+
+/* Augmented block under columns [col0, col0+ncols): aug[r + (j-col0)*ld] = (r == 0 && j < N) ? y[j] : 0,
+ * r < 64.  After the factorisation row 0 holds z^T = (L^-1 y)^T for those columns. */
+int bgp_aug_rows_dev(bgp_handle* h, const double* y_dev, int64_t N, int64_t col0, int64_t ncols,
+                     double* aug_dev, int64_t ld);
+
+/* Factor one column panel in place: panel_dev points at the panel's diagonal element, `nrows` rows
+ * from there down (including augmented rows), `nbk` columns (multiple of 64, <= nb_outer).
+ * inv_dev receives the nbk/64 inverted 64x64 diagonal tiles.  Synchronous; *info_out = 0 or the
+ * 1-based index (within the panel) of the first non-positive pivot. */
+int bgp_factor_panel_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t nrows, int nbk,
+                         double* inv_dev, int* info_out);
+
+/* E_K <- E_K L_KK^-T for a row block E_K[me, nbk] against a factored panel's diagonal block. */
+int bgp_solve_panel_dev(bgp_handle* h, double* E_dev, int64_t lde, int64_t me, const double* Lkk_dev,
+                        int64_t ld, int nbk, const double* inv_dev);
+
+/* bgp_gemm_nt_sub_dev without the trailing synchronisation. */
+int bgp_gemm_nt_sub_async_dev(bgp_handle* h, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                              const double* B_dev, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower);
+
+/* out_host[0] = sum_{i<n} log A[i + i*ld] (half log-determinant of a factored diagonal block). Synchronous. */
+int bgp_diag_logsum_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t n, double* out_host);
+
+/* out_dev[m] = sum_{i<n} E[m + i*lde] * (vec_dev ? vec_dev[i] : E[m + i*lde]),  m < M. */
+int bgp_rowdot_dev(bgp_handle* h, const double* E_dev, int64_t lde, int64_t M, int64_t n, const double* vec_dev,
+                   double* out_dev);
+
+/* Wait for everything enqueued on the handle's streams. */
+int bgp_sync(bgp_handle* h);
+
 #ifdef __cplusplus
 }
 #endif
