@@ -302,6 +302,15 @@ class BatteryCellGP:
         """``-mll`` with ``mll = lml / N`` - the loss of ``src/gp/training.py:29-30,39-40``."""
         return -self.fit() / self.train_targets.shape[0]
 
+    def neg_mll_and_raw_grad(self):
+        """``(loss, d loss / d raw)`` with ``loss = -lml / N``: the LML gradient comes from the GPU
+        (``bgp_lml_grad``), the raw-parameter chain rule (sigmoid / softplus) is applied here - together
+        what ``loss.backward()`` yields in ``src/gp/training.py:41``."""
+        n = self.train_targets.shape[0]
+        lml = self.fit()
+        g_hyp = self.engine().lml_grad()
+        return -lml / n, -(g_hyp * self.dvalue_draw()) / n
+
     def close(self):
         if self._engine is not None:
             self._engine.close()

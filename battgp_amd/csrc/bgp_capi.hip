@@ -343,6 +343,8 @@ void free_problem(bgp_handle* h) {
   dev_free(h, &h->dy, h->N);
   dev_free(h, &h->dE, h->E_rows_cap * h->Npad);
   h->E_rows_cap = 0;
+  dev_free(h, &h->dB, h->lda * h->Npad);
+  dev_free(h, &h->dS, h->lda * h->Npad);
   h->N = h->Npad = h->lda = 0;
   h->D = 0;
   h->fitted = false;
@@ -908,6 +910,88 @@ int bgp_sync(bgp_handle* h) {
   if (rc) return rc;
   BGP_HIP(h, hipStreamSynchronize(h->s_main));
   BGP_HIP(h, hipStreamSynchronize(h->s_aux));
+  return 0;
+}
+
+int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->fitted || !grad_out) return bgp_fail(h, -1, "bgp_lml_grad: no successful fit / NULL output");
+  if (ngrad != h->nhyp) return bgp_fail(h, -1, "bgp_lml_grad: expected %d entries, got %d", h->nhyp, ngrad);
+  if ((rc = ensure_alpha(h))) return rc;
+  hipStream_t st = h->s_main;
+  const int64_t N = h->N, n = h->Npad, lda = h->lda, NB = h->nb_outer;
+  if (!h->dB && (rc = dev_alloc(h, &h->dB, lda * n))) return rc;
+  if (!h->dS && (rc = dev_alloc(h, &h->dS, lda * n))) return rc;
+  double *U = h->dB, *S = h->dS;
+  const double* L = h->dA;
+  const double* inv = h->dInv;
+  PhaseTimer t(h, st, BGP_T_SOLVE);
+  // (1) U = I L^-T (upper triangular): the identity pushed through the panel operations row-block-wise;
+  //     a row only becomes active at the panel that contains its diagonal element  -> N^3/3 flop
+  if ((rc = launch_set_identity(h, st, U, lda, n))) return rc;
+  for (int64_t K0 = 0; K0 < n; K0 += NB) {
+    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    const int64_t K1 = K0 + nbk;
+    for (int64_t j = K0; j < K1; j += BGP_IB) {
+      const int64_t act = j + BGP_IB;  // active rows [0, act)
+      double* Uj = U + j * lda;
+      if ((rc = launch_gemm_nt(h, st, 1, 64, Uj, lda, Uj, lda, inv + (j / BGP_IB) * (BGP_IB * BGP_IB), BGP_IB, act,
+                               BGP_IB, BGP_IB, 0)))
+        return rc;
+      const int64_t ncols = K1 - (j + BGP_IB);
+      if (ncols > 0 &&
+          (rc = launch_gemm_nt(h, st, 0, ncols >= 128 ? 128 : 64, U + (j + BGP_IB) * lda, lda, Uj, lda,
+                               L + (j + BGP_IB) + j * lda, lda, act, ncols, BGP_IB, 0)))
+        return rc;
+    }
+    if (n - K1 > 0 && (rc = launch_gemm_nt(h, st, 0, 128, U + K1 * lda, lda, U + K0 * lda, lda, L + K1 + K0 * lda, lda,
+                                           K1, n - K1, nbk, 0)))
+      return rc;
+  }
+  // (2) S = -Sigma^-1 = -U U^T (lower): per k-panel only rows [0, K1) of U are non-zero  -> N^3/3 flop
+  BGP_HIP(h, hipMemsetAsync(S, 0, (size_t)lda * (size_t)n * sizeof(double), st));
+  for (int64_t K0 = 0; K0 < n; K0 += NB) {
+    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    const int64_t K1 = K0 + nbk;
+    if ((rc = launch_gemm_nt(h, st, 0, 128, S, lda, U + K0 * lda, lda, U + K0 * lda, lda, K1, K1, nbk, 1))) return rc;
+  }
+  // (3) fused reduction of 1/2 tr(W dSigma/dtheta)
+  FillParams p;
+  if ((rc = make_fill_params(h, h->D, 0.0, &p))) return rc;
+  const int64_t nblk = grad_blocks(N);
+  const int nacc = grad_nacc();
+  if ((rc = ensure_part(h, nblk * nacc))) return rc;
+  if ((rc = launch_grad_reduce(h, st, p, h->dX, N, S, lda, h->dalpha, h->dpart, h->dscal))) return rc;
+  BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, nacc * sizeof(double), hipMemcpyDeviceToHost, st));
+  if ((rc = t.stop())) return rc;
+  const double* a = h->hscal;
+  const int D = h->D;
+  for (int i = 0; i < ngrad; ++i) grad_out[i] = 0.0;
+  grad_out[0] = 0.5 * a[0];
+  switch (h->kernel_id) {
+    case BGP_KERNEL_BATTGP:
+      grad_out[1] = 0.5 * a[1];
+      grad_out[2] = 0.5 * a[2];
+      // d/dl_d [s_r exp(-sum u^2)], u_d = (x-x')/(l_d sqrt2):  s_r e 2 u_d^2 / l_d
+      for (int d = 1; d < D; ++d) grad_out[2 + d] = 0.5 * h->hyp[2] * 2.0 / h->hyp[2 + d] * a[3 + d];
+      break;
+    case BGP_KERNEL_SCALED_RBF: {
+      grad_out[1] = 0.5 * a[2];
+      double sum = 0.0;
+      for (int d = 0; d < D; ++d) sum += a[3 + d];
+      grad_out[2] = 0.5 * h->hyp[1] * 2.0 / h->hyp[2] * sum;
+    } break;
+    case BGP_KERNEL_ARD_RBF:
+      grad_out[1] = 0.5 * a[2];
+      for (int d = 0; d < D; ++d) grad_out[2 + d] = 0.5 * h->hyp[1] * 2.0 / h->hyp[2 + d] * a[3 + d];
+      break;
+    case BGP_KERNEL_MATERN32:
+      grad_out[1] = 0.5 * a[2];
+      // d/dl_d [s (1+a) e^-a], a = |v|, v_d = sqrt3 (x-x')/l_d:  s e^-a v_d^2 / l_d
+      for (int d = 0; d < D; ++d) grad_out[2 + d] = 0.5 * h->hyp[1] / h->hyp[2 + d] * a[3 + d];
+      break;
+  }
   return 0;
 }
 

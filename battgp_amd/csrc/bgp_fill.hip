@@ -341,6 +341,132 @@ __global__ __launch_bounds__(64) void llt_sample_kernel(FillParams p, const doub
   }
 }
 
+
+// ---- LML gradient reduction ------------------------------------------------------------------
+//   d lml / d theta = 1/2 sum_jk W_jk dSigma_jk/dtheta,   W = alpha alpha^T + S,  S = -Sigma^-1 (lower)
+// One pass over the lower triangle (same 512 x 32 tiling as the fill), kernel derivatives
+// re-evaluated on the fly, NACC partial sums per workgroup (deterministic two-stage reduction):
+//   acc[0] = sum W_jj (j < N)                              -> d/d noise
+//   acc[1] = sum' W_jk * wiener(t_j, t_k)      (K0 only)   -> d/d s_wiener
+//   acc[2] = sum' W_jk * g_jk,  g = exp part ((1+r) e^-r for Matern)      -> d/d outputscale
+//   acc[3+d] = sum' W_jk * h_jk * u_d^2,  h = exp part (e^-r for Matern), u_d = scaled difference
+// where sum' counts each off-diagonal pair twice (symmetry) and the diagonal once.
+constexpr int GR_NACC = 3 + BGP_MAX_DIM;
+
+template <int KID>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const double* __restrict__ x, int64_t n,
+                                                          const double* __restrict__ S, int64_t lds_,
+                                                          const double* __restrict__ alpha, int nti, int ntj,
+                                                          double* __restrict__ part) {
+  constexpr int DD = BGP_MAX_DIM;
+  const int D = p.D;
+  __shared__ double sB[FT_COLS][DD];
+  __shared__ double sAl[FT_COLS];
+  __shared__ double sT[64];
+  __shared__ double sred[4][GR_NACC];
+  if (threadIdx.x < 64) sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
+  double acc[GR_NACC];
+#pragma unroll
+  for (int q = 0; q < GR_NACC; ++q) acc[q] = 0.0;
+
+  int ti, tj;
+  const bool valid_tile = lower_decode((int64_t)blockIdx.x, nti, ntj, ti, tj);
+  if (valid_tile) {
+    const int64_t i0 = (int64_t)ti * FT_ROWS, j0 = (int64_t)tj * FT_COLS;
+    for (int idx = threadIdx.x; idx < FT_COLS * DD; idx += 256) {
+      int c = idx / DD, d = idx % DD;
+      int64_t j = j0 + c;
+      double v = 0.0;
+      if (j < n && d < D) {
+        v = x[j * D + d];
+        if (!(KID == BGP_KERNEL_BATTGP && d == 0)) v *= p.scale[d];
+      }
+      sB[c][d] = v;
+    }
+    if (threadIdx.x < FT_COLS) sAl[threadIdx.x] = (j0 + threadIdx.x < n) ? alpha[j0 + threadIdx.x] : 0.0;
+    const int64_t i = i0 + 2 * (int64_t)threadIdx.x;
+    double a[2][DD];
+    load_point<KID, DD>(x, i, n, D, p, a[0]);
+    load_point<KID, DD>(x, i + 1, n, D, p, a[1]);
+    const double al[2] = {i < n ? alpha[i] : 0.0, i + 1 < n ? alpha[i + 1] : 0.0};
+    __syncthreads();
+    for (int c = 0; c < FT_COLS; ++c) {
+      const int64_t j = j0 + c;
+      if (j >= n) break;
+      double b[DD];
+#pragma unroll
+      for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int64_t ii = i + r;
+        if (ii >= n || ii < j) continue;  // padding / strict upper triangle
+        const double wgt = (ii == j) ? 1.0 : 2.0;
+        const double W = wgt * (al[r] * sAl[c] + S[ii + j * lds_]);
+        if (ii == j) acc[0] += W;
+        double q = 0.0, u2[DD];
+#pragma unroll
+        for (int d = 0; d < DD; ++d) {
+          u2[d] = 0.0;
+          if (d < D && !(KID == BGP_KERNEL_BATTGP && d == 0)) {
+            const double df = a[r][d] - b[d];
+            u2[d] = df * df;
+            q += u2[d];
+          }
+        }
+        double g, hh;
+        if (KID == BGP_KERNEL_MATERN32) {
+          const double rr = sqrt_nonneg(q);
+          hh = exp_nonpos(-rr, sT);
+          g = (1.0 + rr) * hh;
+        } else {
+          hh = exp_nonpos(-q, sT);
+          g = hh;
+        }
+        if (KID == BGP_KERNEL_BATTGP) {
+          const double m = __builtin_fmin(a[r][0], b[0]);
+          const double ad = __builtin_fabs(a[r][0] - b[0]);
+          const double m2 = m * m;
+          acc[1] = __builtin_fma(W, (m2 * m) * (1.0 / 3.0) + (ad * m2) * 0.5, acc[1]);
+        }
+        acc[2] = __builtin_fma(W, g, acc[2]);
+        const double Wh = W * hh;
+#pragma unroll
+        for (int d = 0; d < DD; ++d) acc[3 + d] = __builtin_fma(Wh, u2[d], acc[3 + d]);
+      }
+    }
+  }
+  // workgroup reduction (fixed order)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < GR_NACC; ++q) {
+    double v = acc[q];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) sred[wave][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < GR_NACC)
+    part[(int64_t)blockIdx.x * GR_NACC + threadIdx.x] =
+        (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+}
+
+// out[q] = sum_b part[b * GR_NACC + q]   (one workgroup, fixed order => run-to-run identical)
+__global__ __launch_bounds__(1024) void grad_finish_kernel(const double* __restrict__ part, int64_t nblocks,
+                                                           double* __restrict__ out) {
+  __shared__ double red[1024];
+  for (int q = 0; q < GR_NACC; ++q) {
+    double v = 0.0;
+    for (int64_t b = threadIdx.x; b < nblocks; b += 1024) v += part[b * GR_NACC + q];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[q] = red[0];
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 #define BGP_KID_SWITCH(kid, CALL)                                  \
@@ -378,6 +504,22 @@ int launch_llt_sample(bgp_handle* h, hipStream_t st, const FillParams& p, const 
   dim3 grid((unsigned)nsample), block(64);
   BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((llt_sample_kernel<KID_>), grid, block, 0, st, p, x, L, lda,
                                            n, diag_add, nsample, out_err));
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int grad_nacc() { return GR_NACC; }
+
+int64_t grad_blocks(int64_t n) { return lower_blocks((int)((n + FT_ROWS - 1) / FT_ROWS)); }
+
+int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n,
+                       const double* S, int64_t lds_, const double* alpha, double* part, double* out) {
+  const int nti = (int)((n + FT_ROWS - 1) / FT_ROWS), ntj = (int)((n + FT_COLS - 1) / FT_COLS);
+  const int64_t nb = lower_blocks(nti);
+  BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((grad_reduce_kernel<KID_>), dim3((unsigned)nb), dim3(256), 0, st, p, x, n, S,
+                                           lds_, alpha, nti, ntj, part));
+  BGP_HIP(h, hipGetLastError());
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(1024), 0, st, part, nb, out);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

@@ -49,6 +49,8 @@ struct bgp_handle {
   double* dInv = nullptr;    // [Npad/64][64*64] inverses of the diagonal tiles of L
   double* dz = nullptr;      // [Npad] z = L^-1 y (zero in the padding)
   double* dalpha = nullptr;  // [Npad]
+  double* dB = nullptr;      // gradient workspace: U = L^-T (upper), [lda, Npad]; allocated on first bgp_lml_grad
+  double* dS = nullptr;      // gradient workspace: S = -Sigma^-1 (lower), [lda, Npad]
   double* dE = nullptr;      // [lde, Npad] cross-covariance row block (queries x train)
   int64_t E_rows_cap = 0;
   double* dXq = nullptr;     // [M, D]
@@ -109,3 +111,8 @@ int launch_norm2(bgp_handle* h, hipStream_t st, const double* a, const double* b
                  double* out);  // out[0] = sum (a-b)^2 or sum a^2
 int launch_copy_strided(bgp_handle* h, hipStream_t st, const double* src, int64_t n, double* dst,
                         int64_t ld_dst, int64_t npad);  // dst[i*ld_dst] = src[i] (i<n) else 0
+int grad_nacc();
+int64_t grad_blocks(int64_t n);
+int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n,
+                       const double* S, int64_t lds_, const double* alpha, double* part, double* out);
+int launch_set_identity(bgp_handle* h, hipStream_t st, double* B, int64_t ld, int64_t n);

@@ -514,6 +514,11 @@ __global__ __launch_bounds__(1024) void norm2_kernel(const double* __restrict__ 
   if (threadIdx.x == 0) out[0] = r0[0];
 }
 
+__global__ __launch_bounds__(256) void set_diag_one_kernel(double* __restrict__ B, int64_t ld, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) B[i + i * ld] = 1.0;
+}
+
 // augmented block below the matrix: row 0 = y^T (zero in the padding), other rows zero
 __global__ __launch_bounds__(256) void aug_rows_kernel(const double* __restrict__ y, int64_t n,
                                                        double* __restrict__ Aaug, int64_t lda, int64_t ncols,
@@ -647,6 +652,13 @@ int launch_copy_strided(bgp_handle* h, hipStream_t st, const double* src, int64_
                         int64_t ld_dst, int64_t npad) {
   hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st, src, n,
                      dst, ld_dst, npad);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_set_identity(bgp_handle* h, hipStream_t st, double* B, int64_t ld, int64_t n) {
+  BGP_HIP(h, hipMemsetAsync(B, 0, (size_t)ld * (size_t)n * sizeof(double), st));
+  hipLaunchKernelGGL(set_diag_one_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, ld, n);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

@@ -133,6 +133,12 @@ class ExactGPEngine:
         self.hyp = hyp.copy()
         return self._after_fit(lml, jit)
 
+    def lml_grad(self) -> np.ndarray:
+        """d lml / d hyp (same layout as ``hyp``) at the last fit, computed on the GPU."""
+        g = np.zeros(self.hyp.size, dtype=np.float64)
+        self._check(self._lib.bgp_lml_grad(self._h, dptr(g), g.size), "bgp_lml_grad")
+        return g
+
     def predict(self, xq: np.ndarray, want_var: bool = True, min_var: float = 1e-10):
         xq = np.ascontiguousarray(xq, dtype=np.float64)
         if xq.ndim == 1:

@@ -305,6 +305,7 @@ class ShardedExactGP:
             self._reduce(blk, owner)
             if self.rank == owner:
                 ek[: nbk * lde] = blk
+                be.after_comm()  # container copy (torch stream) must land before the engine's kernels read it
                 be.solve_panel(ek, lde, 0, mpad, self.store, ld, self.lcol0[k], c0, nbk, self.inv[k])
                 rest = lay.npad - (c0 + nbk)
                 if rest > 0:
@@ -312,9 +313,11 @@ class ShardedExactGP:
                 be.rowdot(ek, lde, mpad, nbk, self.z[c0 : c0 + nbk], tmp)
                 be.sync()
                 mean_p += tmp
+                be.after_comm()
                 be.rowdot(ek, lde, mpad, nbk, None, tmp)
                 be.sync()
                 var_p += tmp
+                be.after_comm()  # ... and the accumulations before `tmp` / `w` are touched again
         self._allreduce(mean_p)
         self._allreduce(var_p)
         mean = be.to_host(mean_p)[:m]

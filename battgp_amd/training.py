@@ -3,11 +3,10 @@ as ``src/gp/training.py`` (``train_exact_gp_adam`` :11-67, ``train_exact_gp_lbfg
 ``train_exact_gp_botorch`` :70-105).
 
 Each iteration evaluates ``loss = -mll = -lml / N`` with ONE resident re-fit on the GPU
-(``bgp_refit``: fill + jittered Cholesky + solves, no re-upload).  The gradient w.r.t. the raw
-(unconstrained) parameters - what ``loss.backward()`` gives the reference - is taken by central
-finite differences of that loss in raw space for now; the analytic
-``1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta)`` kernels are the next row of the scope table
- and will replace it without changing this file's interface.
+(``bgp_refit``: fill + jittered Cholesky, no re-upload) and its gradient with ``bgp_lml_grad``
+(``1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta)``: Sigma^-1 formed by two more N^3/3 MFMA passes
+plus one fused reduction pass); the chain rule to the raw (unconstrained) parameters - what
+``loss.backward()`` gives the reference - is applied on the host (``BatteryCellGP.neg_mll_and_raw_grad``).
 """
 
 from __future__ import annotations
@@ -22,7 +21,14 @@ def _loss(model: BatteryCellGP, raw: np.ndarray) -> float:
     return model.neg_mll()
 
 
-def _loss_and_grad(model: BatteryCellGP, raw: np.ndarray, rel_step: float = 1e-4):
+def _loss_and_grad(model: BatteryCellGP, raw: np.ndarray):
+    model.set_raw_vector(raw)
+    return model.neg_mll_and_raw_grad()
+
+
+def _loss_and_grad_fd(model: BatteryCellGP, raw: np.ndarray, rel_step: float = 1e-4):
+    """Central finite differences of the GPU loss in raw space (2 x nparam re-fits): kept as an
+    independent check of the analytic gradient, not used by the trainers."""
     f0 = _loss(model, raw)
     g = np.zeros_like(raw)
     for i in range(raw.size):

@@ -105,6 +105,14 @@ int bgp_fit_dev(bgp_handle* h, const double* X_dev, const double* y_dev, int64_t
  * of the optimiser loops in src/gp/training.py:39-41,126-145. */
 int bgp_refit(bgp_handle* h, const double* hyp, int nhyp, double* lml_out, double* jitter_out);
 
+/* Gradient of the LML of the last fit w.r.t. the hyper-parameter vector (same layout as hyp):
+ *   d lml / d theta_i = 1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta_i).
+ * Sigma^-1 is formed explicitly on the GPU (U = L^-T, then U U^T: 2/3 N^3 flop on the MFMA kernel, two
+ * extra N^2 buffers kept on the handle), followed by one fused pass that re-evaluates the kernel
+ * derivatives.  Replaces the autograd backward of src/gp/training.py:41 (loss.backward()) up to the
+ * factor -1/N and the raw-parameter chain rule, which stay on the host. */
+int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad);
+
 /* PREDICT: posterior of the latent f at Xq[M,D] (no noise added):
  *   mean = K_*X alpha;  var = diag(K_**) - colsumsq(L^-1 K_X*), floored at min_var
  *   (pass min_var < 0 for the unclamped diagonal of src/gp/standard_models.py:48;

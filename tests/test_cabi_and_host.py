@@ -168,7 +168,11 @@ def test_training_loops_follow_reference_stop_rule(monkeypatch):
     def fake_neg_mll():
         return 1.0 + float(np.sum((model.raw_vector() - target) ** 2))
 
+    def fake_loss_and_grad():
+        return fake_neg_mll(), 2.0 * (model.raw_vector() - target)
+
     monkeypatch.setattr(model, "neg_mll", fake_neg_mll)
+    monkeypatch.setattr(model, "neg_mll_and_raw_grad", fake_loss_and_grad)
     losses = training.train_exact_gp_adam(model, max_iter=200, rel_ftol=0.0, loss_scale=10, lr=0.05, messages=False)
     assert losses.shape == (201,) and not np.isnan(losses).any()
     assert losses[0] == pytest.approx(10 * (1 + 6 * 0.25))

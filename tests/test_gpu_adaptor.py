@@ -180,3 +180,13 @@ def test_train_hyperparameters_decreases_loss_and_updates_params(monkeypatch):
     monkeypatch.setitem(cfg.HYPER_OPT_PARAMS, "opt_algorithm", "nope")
     with pytest.raises(ValueError, match="not implemented"):
         cell.train_hyperparameters(messages=False)
+
+
+def test_analytic_raw_gradient_matches_finite_differences():
+    x, y = synthetic.make_cell_data(300, seed=8)
+    cell = BatteryCellGP_Full(x, y, 1, device=0, noise_variance=(1e-5,), outputscale_rbf=0.05)
+    raw = cell.model.raw_vector()
+    f, g = training._loss_and_grad(cell.model, raw)
+    f_fd, g_fd = training._loss_and_grad_fd(cell.model, raw, rel_step=1e-5)
+    assert f == pytest.approx(f_fd, rel=1e-12)
+    assert np.allclose(g, g_fd, rtol=2e-4, atol=1e-8 * np.abs(g_fd).max()), (g, g_fd)

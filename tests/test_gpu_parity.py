@@ -320,3 +320,43 @@ def test_size_independent_properties_medium_n():
     m3 = e.predict(xq, want_var=False)
     e.close()
     assert rel_err(m3, 3.0 * m1) < 1e-9
+
+
+@pytest.mark.parametrize("kid", [K.KERNEL_BATTGP, K.KERNEL_SCALED_RBF, K.KERNEL_MATERN32, K.KERNEL_ARD_RBF])
+@pytest.mark.parametrize("n", [24, 700])
+def test_lml_gradient_matches_oracle(kid, n):
+    from oracle.exact_gp import lml_and_grad
+
+    rng = np.random.default_rng(n + kid)
+    x = np.column_stack([np.sort(rng.uniform(0, 5, n)), rng.normal(size=(n, 3))])
+    y = rng.normal(size=n)
+    hyp = {
+        K.KERNEL_BATTGP: np.array([0.1, 0.5, 1.3, 0.8, 1.1, 1.7]),
+        K.KERNEL_SCALED_RBF: np.array([0.1, 1.3, 1.5]),
+        K.KERNEL_MATERN32: np.array([0.1, 1.3, 2.0, 0.8, 1.1, 1.7]),
+        K.KERNEL_ARD_RBF: np.array([0.1, 1.3, 2.0, 0.8, 1.1, 1.7]),
+    }[kid]
+    lml_ref, g_ref = lml_and_grad(kid, hyp, x, y)
+    e = ExactGPEngine(kid, hyp)
+    lml = e.fit(x, y)
+    g = e.lml_grad()
+    g2 = e.lml_grad()  # workspaces are reused; result is run-to-run identical
+    m, v = e.predict(x[:5])  # the fit is still usable after the gradient
+    e.close()
+    assert abs(lml - lml_ref) < 1e-9 * abs(lml_ref)
+    assert np.allclose(g, g_ref, rtol=1e-7, atol=1e-9 * np.abs(g_ref).max()), (g, g_ref)
+    assert np.array_equal(g, g2)
+    assert np.all(np.isfinite(m)) and np.all(v > 0)
+
+
+def test_lml_gradient_production_hyperparameters():
+    from oracle.exact_gp import lml_and_grad
+
+    x, y = synthetic.make_cell_data(1500, seed=4)
+    lml_ref, g_ref = lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    e.fit(x, y)
+    g = e.lml_grad()
+    e.close()
+    # entries span 20 orders of magnitude (d/ds_w ~ 1e13): compare each relative to itself
+    assert np.allclose(g, g_ref, rtol=1e-5), (g, g_ref)
