@@ -227,11 +227,14 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t nr
     const int64_t K1 = K0 + nbk;
     const int64_t rows_trail = n - K1;
     if ((rc = factor_panel(h, sp, A, nrows, lda, inv, dinfo, K0, nbk))) return rc;
+    // deep rank-NB updates accumulate through L2 atomics (no C read in the tile prologue: +4 % at k = 512);
+    // shallow ones keep the read-modify-write form (atomics lose below k ~ 256)
+    const int tmode = (nbk >= 256 && h->lookahead != 3) ? 2 : 0;
     if (rows_trail > 0) {
       double* P = A + K1 + K0 * lda;
       if (!la) {
         if ((rc = tt.begin(st))) return rc;
-        rc = launch_gemm_nt(h, st, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail + extra, rows_trail, nbk, 1, dinfo);
+        rc = launch_gemm_nt(h, st, tmode, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail + extra, rows_trail, nbk, 1, dinfo);
         if (rc) return rc;
         if ((rc = tt.end(st, (double)rows_trail, (double)rows_trail, (double)nbk, true))) return rc;
       } else {
@@ -244,7 +247,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t nr
         // la(k) on sp rewrites columns that rest(k-1) also updated: order it after rest(k-1)
         if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + 2 * (size_t)(step - 1)], 0));
         if ((rc = tt.begin(sp))) return rc;
-        rc = launch_gemm_nt(h, sp, 0, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail + extra, nbn, nbk, 1, dinfo);
+        rc = launch_gemm_nt(h, sp, tmode, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail + extra, nbn, nbk, 1, dinfo);
         if (rc) return rc;
         if ((rc = tt.end(sp, (double)rows_trail, (double)nbn, (double)nbk, false))) return rc;
         // rest(k) on st: everything right of the next panel
@@ -252,12 +255,8 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t nr
         if (rows_rest > 0) {
           const double* P2 = A + K2 + K0 * lda;
           if ((rc = tt.begin(st))) return rc;
-          // stagger the first round when the launch spans many rounds of equal tiles (see kernel)
-          const int64_t nt_rest = (rows_rest + 127) / 128;
-          const int64_t rounds = nt_rest * (nt_rest + 1) / 2 / 512;
-          const int stagger = (rounds >= 8) ? (int)((nbk / 16) * 3.6 / 8.0 / 1.7 + 1.0) : 0;
-          rc = launch_gemm_nt(h, st, 0, 128, A + K2 + K2 * lda, lda, P2, lda, P2, lda, rows_rest + extra, rows_rest, nbk,
-                              1, dinfo, stagger);
+          rc = launch_gemm_nt(h, st, tmode, 128, A + K2 + K2 * lda, lda, P2, lda, P2, lda, rows_rest + extra, rows_rest,
+                              nbk, 1, dinfo);
           if (rc) return rc;
           if ((rc = tt.end(st, (double)rows_rest, (double)rows_rest, (double)nbk, true))) return rc;
         }

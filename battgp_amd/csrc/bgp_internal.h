@@ -85,7 +85,7 @@ int launch_fill(bgp_handle* h, hipStream_t st, const FillParams& p, const double
                 int64_t nvalid1, int64_t nvalid2);
 int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, int64_t ldc,
                    const double* A, int64_t lda, const double* B, int64_t ldb, int64_t m, int64_t n,
-                   int64_t k, int lower, const int* abort_flag = nullptr, int stagger = 0);
+                   int64_t k, int lower, const int* abort_flag = nullptr);
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv,
                       int* info, int col0, int nvalid);
 int launch_fit_scalars(bgp_handle* h, hipStream_t st, const double* A, int64_t lda, const double* z,

@@ -3,6 +3,7 @@
 // Everything is column-major.  The one hot kernel is gemm_nt_kernel:
 //     C[m,n] -= A[m,k] * B[n,k]^T        (MODE 0; `lower` keeps only tiles touching i >= j)
 //     C[m,n]  = A[m,k] * B[n,k]^T        (MODE 1; C may alias A: used as TRSM-by-inverse)
+//     C[m,n] += -(A B^T) by L2 atomics   (MODE 2; no C read: the deep rank-NB trailing updates)
 // built on v_mfma_f64_16x16x4_f64.  It serves the SYRK trailing update of the Cholesky, the
 // in-panel updates, the TRSM by inverted 64x64 diagonal tiles, the triangular solve of the
 // query block (posterior variance) and the full-covariance downdate.
@@ -74,8 +75,7 @@ template <int TM, int TN, int MODE, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc, const double* A,
                                                          int64_t lda, const double* B, int64_t ldb,
                                                          int64_t m, int64_t n, int k, int lower, int nti,
-                                                         int ntj, const int* __restrict__ abort_flag,
-                                                         int stagger) {
+                                                         int ntj, const int* __restrict__ abort_flag) {
   constexpr int LDA_S = TM + 16;  // (ld % 32 == 16) => the two 16-lane groups of a ds_read_b64
   constexpr int LDB_S = TN + 16;  //  half-wave hit disjoint bank halves: conflict-free
   constexpr int MI = TM / 32, MJ = TN / 32;          // 16x16 MFMA tiles per wave along i / j
@@ -92,16 +92,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
   // A failed pivot earlier in the factorisation poisons the rest of the enqueued pipeline:
   // every later kernel sees the flag and returns at once (no host round trip needed).
   if (abort_flag != nullptr && *abort_flag != 0) return;
-
-  // Equal tiles finish in lock-step "rounds": CU slots would free only every ~130 us and the
-  // dependent panel kernels of the look-ahead stream would advance one kernel per round.
-  // Spreading the start of the first resident workgroups over 8 phases makes slots free
-  // continuously for the whole launch (measured: a waiting kernel gets a slot in ~12 us
-  // instead of ~205 us).  Speed only; no effect on results.
-  if (stagger > 0 && blockIdx.x < 512) {
-    const int ns = (int)((blockIdx.x >> 3) & 7) * stagger;  // b % 8 selects the XCD: vary the phase WITHIN each XCD
-    for (int q = 0; q < ns; ++q) __builtin_amdgcn_s_sleep(64);
-  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -130,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
       regB[q] = *reinterpret_cast<const double2*>(gB_safe + (koff + q * CSB) * ldb);
   };
   const double za = a_in ? 1.0 : 0.0;
-  const double zb = b_in ? ((MODE == 0) ? -1.0 : 1.0) : 0.0;  // MODE 0 stages -B
+  const double zb = b_in ? ((MODE == 0 || MODE == 2) ? -1.0 : 1.0) : 0.0;  // MODE 0/2 stage -B
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NLA; ++q)
@@ -227,7 +217,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t j = j0 + wj * (TN / 2) + a * 16 + l4 + 4 * r;
-        if (i < m && j < n) C[i + j * ldc] = acc[a][b][r];
+        if (i < m && j < n) {
+          if (MODE == 2) {
+            // accumulators started at 0 and hold -A B^T: one fire-and-forget L2 atomic per element
+            // (exactly one add per element per launch => deterministic); no C read in the prologue
+            unsafeAtomicAdd(C + i + j * ldc, acc[a][b][r]);  // global_atomic_add_f64, no return
+          } else {
+            C[i + j * ldc] = acc[a][b][r];
+          }
+        }
       }
     }
   }
@@ -546,7 +544,7 @@ __global__ __launch_bounds__(256) void copy_strided_kernel(const double* __restr
 
 int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, int64_t ldc,
                    const double* A, int64_t lda, const double* B, int64_t ldb, int64_t m, int64_t n,
-                   int64_t k, int lower, const int* abort_flag, int stagger) {
+                   int64_t k, int lower, const int* abort_flag) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   if ((k % BK) != 0) return bgp_fail(h, -1, "gemm_nt: k=%lld not a multiple of %d", (long long)k, BK);
   if ((m & 1) || (n & 1) || (lda & 1) || (ldb & 1))
@@ -561,13 +559,16 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
   dim3 grid((unsigned)blocks), block(256);
   if (tn == 128 && mode == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj, abort_flag, stagger);
+                       (int)k, lower, nti, ntj, abort_flag);
+  else if (tn == 128 && mode == 2)
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
+                       (int)k, lower, nti, ntj, abort_flag);
   else if (tn == 64 && mode == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj, abort_flag, stagger);
+                       (int)k, lower, nti, ntj, abort_flag);
   else if (tn == 64 && mode == 1)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj, abort_flag, stagger);
+                       (int)k, lower, nti, ntj, abort_flag);
   else
     return bgp_fail(h, -1, "gemm_nt: unsupported variant tn=%d mode=%d", tn, mode);
   BGP_HIP(h, hipGetLastError());

@@ -122,6 +122,7 @@ def main() -> None:
     ap.add_argument("--m", type=int, default=300, help="query points (battgp_full.py:98)")
     ap.add_argument("--kernel", default="battgp", choices=["battgp", "matern32"])
     ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
+    ap.add_argument("--lookahead", type=int, default=-1, help="0 = off, 1 = on + staggered first round (default), 2 = on, no stagger")
     ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--target-n", type=int, default=131072,
@@ -161,6 +162,8 @@ def main() -> None:
     eng = ExactGPEngine(kernel_id, hyp, device=local_rank)
     if args.nb > 0:
         eng.set_options(nb_outer=args.nb)
+    if args.lookahead >= 0:
+        eng.set_options(lookahead=args.lookahead)
 
     def step():
         eng.fit_device(tx.data_ptr(), ty.data_ptr(), n, 4)
