@@ -27,6 +27,14 @@ SIGNATURES = {
     "bgp_fit": (C.c_int, [handle_p, c_double_p, c_double_p, C.c_int64, C.c_int, c_double_p, c_double_p]),
     "bgp_fit_dev": (C.c_int, [handle_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, c_double_p, c_double_p]),
     "bgp_refit": (C.c_int, [handle_p, c_double_p, C.c_int, c_double_p, c_double_p]),
+    "bgp_fit_predict": (
+        C.c_int,
+        [handle_p, c_double_p, c_double_p, C.c_int64, C.c_int, c_double_p, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double],
+    ),
+    "bgp_fit_predict_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, c_double_p, c_double_p, C.c_void_p, C.c_void_p, C.c_double],
+    ),
     "bgp_lml_grad": (C.c_int, [handle_p, c_double_p, C.c_int]),
     "bgp_predict": (C.c_int, [handle_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_double]),
     "bgp_predict_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double]),

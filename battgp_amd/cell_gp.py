@@ -289,8 +289,19 @@ class BatteryCellGP:
 
     def __call__(self, x) -> Posterior:
         xq = torch.as_tensor(x, dtype=torch.float64)
-        self.fit()
-        mean, var = self.engine().predict(xq.detach().cpu().numpy(), want_var=True, min_var=MIN_VARIANCE)
+        xq_host = xq.detach().cpu().numpy()
+        if not self._fitted:
+            # the reference builds K lazily and factorises inside the first model(x) call
+            # (battcellgp_full.py:171-173): do the same in ONE pass - the query rows ride through the
+            # factorisation (bgp_fit_predict), no separate triangular solve
+            eng = self.engine()
+            eng.set_hyp(self.hyp_vector())
+            xt, yt = self.train_inputs[0], self.train_targets
+            self.lml, mean, var = eng.fit_predict(xt.cpu().numpy(), yt.cpu().numpy(), xq_host, True, MIN_VARIANCE)
+            self.jitter = eng.jitter
+            self._fitted = True
+            return Posterior(mean, var, xq.device)
+        mean, var = self.engine().predict(xq_host, want_var=True, min_var=MIN_VARIANCE)
         return Posterior(mean, var, xq.device)
 
     def posterior_mean(self, x) -> np.ndarray:

@@ -349,19 +349,22 @@ void free_problem(bgp_handle* h) {
   h->fitted = false;
 }
 
-int alloc_problem(bgp_handle* h, int64_t N, int D) {
-  if (h->N == N && h->D == D && h->dA) return 0;
+int alloc_problem(bgp_handle* h, int64_t N, int D, int64_t Mride) {
+  const int64_t aug_need = BGP_AUG + round_up(Mride, 64);
+  if (h->N == N && h->D == D && h->dA && h->aug_cap >= aug_need) return 0;
   free_problem(h);
   const int64_t Npad = round_up(N, BGP_IB);
-  // column stride: avoid large power-of-two strides (all columns of a tile in one HBM channel)
-  // + 64 rows for the augmented block (row Npad = y^T); avoid large power-of-two column strides
-  // (all columns of a tile in one HBM channel)
-  int64_t lda = Npad + BGP_AUG;
+  // rows below the matrix: 64 for the augmented block (row Npad = y^T) + the query rows that ride
+  // through the factorisation (bgp_fit_predict); avoid large power-of-two column strides (all
+  // columns of a tile in one HBM channel)
+  int64_t lda = Npad + aug_need;
   if (lda >= 2048 && (lda % 512) == 0) lda += 64;
   h->N = N;
   h->D = D;
   h->Npad = Npad;
   h->lda = lda;
+  h->aug_cap = aug_need;
+  h->aug_used = BGP_AUG;
   int rc;
   if ((rc = dev_alloc(h, &h->dX, N * D))) return rc;
   if ((rc = dev_alloc(h, &h->dy, N))) return rc;
@@ -376,11 +379,16 @@ int alloc_problem(bgp_handle* h, int64_t N, int D) {
 }
 
 // fill + jittered Cholesky + solves + lml on the resident X, y
-int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out) {
+// Mride > 0: the first Mride rows of dXq are query points whose cross-covariance rows ride through the
+// factorisation below the augmented y block and come out as V^T = K_*X L^-T (no separate solve pass)
+int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mride = 0) {
   hipStream_t st = h->s_main;
   const int64_t N = h->N, Npad = h->Npad, lda = h->lda;
   h->fitted = false;
-  h->times[BGP_T_FILL] = h->times[BGP_T_POTRF] = 0.0;
+  h->times[BGP_T_FILL] = h->times[BGP_T_POTRF] = h->times[BGP_T_CROSS] = 0.0;
+  const int64_t ride_rows = round_up(Mride, 64);
+  if (BGP_AUG + ride_rows > h->aug_cap) return bgp_fail(h, -1, "internal: no room for %lld riding rows", (long long)Mride);
+  h->aug_used = BGP_AUG + ride_rows;
   double jitter = 0.0;
   int info = 0;
   for (int attempt = 0; attempt <= h->max_tries; ++attempt) {
@@ -394,9 +402,15 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out) {
       if ((rc = launch_aug_rows(h, st, h->dy, N, h->dA + Npad, lda, Npad, BGP_AUG))) return rc;
       if ((rc = t.stop())) return rc;
     }
+    if (Mride > 0) {
+      PhaseTimer t(h, st, BGP_T_CROSS, true);
+      rc = launch_fill(h, st, p, h->dXq, ride_rows, h->dX, Npad, h->dA + Npad + BGP_AUG, lda, 0, 0, Mride, N);
+      if (rc) return rc;
+      if ((rc = t.stop())) return rc;
+    }
     {
       PhaseTimer t(h, st, BGP_T_POTRF, true);
-      rc = potrf_driver(h, st, h->dA, Npad, Npad + BGP_AUG, lda, h->dInv, h->dinfo, &info, true);
+      rc = potrf_driver(h, st, h->dA, Npad, Npad + h->aug_used, lda, h->dInv, h->dinfo, &info, true);
       if (rc) return rc;
       if ((rc = t.stop())) return rc;
     }
@@ -439,15 +453,8 @@ int ensure_alpha(bgp_handle* h) {
   return 0;
 }
 
-int ensure_query(bgp_handle* h, int64_t M) {
-  const int64_t Mpad = round_up(M, 16);
-  if (Mpad > h->E_rows_cap) {
-    dev_free(h, &h->dE, h->E_rows_cap * h->Npad);
-    h->E_rows_cap = 0;
-    int rc = dev_alloc(h, &h->dE, Mpad * h->Npad);
-    if (rc) return rc;
-    h->E_rows_cap = Mpad;
-  }
+// small per-query buffers (points, results, partial sums)
+int ensure_query_small(bgp_handle* h, int64_t M) {
   if (M * h->D > h->Xq_cap) {
     dev_free(h, &h->dXq, h->Xq_cap);
     h->Xq_cap = 0;
@@ -463,6 +470,37 @@ int ensure_query(bgp_handle* h, int64_t M) {
     h->out_cap = 2 * M;
   }
   return ensure_part(h, ((h->Npad + 511) / 512 + 1) * M);
+}
+
+// + the [Mpad, Npad] block of the separate triangular-solve pass
+int ensure_query(bgp_handle* h, int64_t M) {
+  const int64_t Mpad = round_up(M, 16);
+  if (Mpad > h->E_rows_cap) {
+    dev_free(h, &h->dE, h->E_rows_cap * h->Npad);
+    h->E_rows_cap = 0;
+    int rc = dev_alloc(h, &h->dE, Mpad * h->Npad);
+    if (rc) return rc;
+    h->E_rows_cap = Mpad;
+  }
+  return ensure_query_small(h, M);
+}
+
+// posterior of the Mride riding queries from the factor's extra rows: mean = V^T z, var = k_** - rowsumsq(V^T)
+int ride_posterior(bgp_handle* h, int64_t M, bool want_var, double min_var) {
+  hipStream_t st = h->s_main;
+  FillParams p;
+  int rc = make_fill_params(h, h->D, 0.0, &p);
+  if (rc) return rc;
+  const double* E = h->dA + h->Npad + BGP_AUG;
+  PhaseTimer t(h, st, BGP_T_VAR);
+  int nch = 0;
+  if ((rc = launch_rowdot(h, st, E, h->lda, M, h->Npad, h->dz, h->dpart, &nch))) return rc;
+  if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, nullptr, &p, -1.0, h->dout))) return rc;
+  if (want_var) {
+    if ((rc = launch_rowdot(h, st, E, h->lda, M, h->Npad, nullptr, h->dpart, &nch))) return rc;
+    if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, h->dXq, &p, min_var, h->dout + M))) return rc;
+  }
+  return t.stop();
 }
 
 // dXq holds the queries; results land in dout[0..M) (mean) and dout[M..2M) (var)
@@ -617,7 +655,7 @@ static int fit_common(bgp_handle* h, const double* X, const double* y, int64_t N
   if (!X || !y || N < 1) return bgp_fail(h, -1, "bgp_fit: bad arguments (N=%lld)", (long long)N);
   FillParams p;
   if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
-  if ((rc = alloc_problem(h, N, D))) return rc;
+  if ((rc = alloc_problem(h, N, D, 0))) return rc;
   {
     PhaseTimer t(h, h->s_main, BGP_T_H2D);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -644,6 +682,50 @@ int bgp_refit(bgp_handle* h, const double* hyp, int nhyp, double* lml_out, doubl
   if (!h->dA || h->N < 1) return bgp_fail(h, -1, "bgp_refit: no resident problem (call bgp_fit first)");
   if ((rc = bgp_set_kernel(h, h->kernel_id, hyp, nhyp))) return rc;
   return fit_resident(h, lml_out, jitter_out);
+}
+
+static int fit_predict_common(bgp_handle* h, const double* X, const double* y, int64_t N, int D, const double* Xq,
+                              int64_t M, double* lml_out, double* jitter_out, double* mean, double* var,
+                              double min_var, bool on_device) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!X || !y || N < 1 || !Xq || M < 1 || !mean)
+    return bgp_fail(h, -1, "bgp_fit_predict: bad arguments (N=%lld M=%lld)", (long long)N, (long long)M);
+  FillParams p;
+  if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
+  if ((rc = alloc_problem(h, N, D, M))) return rc;
+  if ((rc = ensure_query_small(h, M))) return rc;
+  const hipMemcpyKind kin = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const hipMemcpyKind kout = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  {
+    PhaseTimer t(h, h->s_main, BGP_T_H2D);
+    BGP_HIP(h, hipMemcpyAsync(h->dX, X, (size_t)N * D * sizeof(double), kin, h->s_main));
+    BGP_HIP(h, hipMemcpyAsync(h->dy, y, (size_t)N * sizeof(double), kin, h->s_main));
+    BGP_HIP(h, hipMemcpyAsync(h->dXq, Xq, (size_t)M * D * sizeof(double), kin, h->s_main));
+    if ((rc = t.stop())) return rc;
+  }
+  if ((rc = fit_resident(h, lml_out, jitter_out, M))) return rc;
+  if ((rc = ride_posterior(h, M, var != nullptr, min_var))) return rc;
+  {
+    PhaseTimer t(h, h->s_main, BGP_T_D2H);
+    BGP_HIP(h, hipMemcpyAsync(mean, h->dout, (size_t)M * sizeof(double), kout, h->s_main));
+    if (var) BGP_HIP(h, hipMemcpyAsync(var, h->dout + M, (size_t)M * sizeof(double), kout, h->s_main));
+    if ((rc = t.stop())) return rc;
+  }
+  return 0;
+}
+
+int bgp_fit_predict(bgp_handle* h, const double* X_host, const double* y_host, int64_t N, int D,
+                    const double* Xq_host, int64_t M, double* lml_out, double* jitter_out, double* mean_out,
+                    double* var_out, double min_var) {
+  return fit_predict_common(h, X_host, y_host, N, D, Xq_host, M, lml_out, jitter_out, mean_out, var_out, min_var,
+                            false);
+}
+
+int bgp_fit_predict_dev(bgp_handle* h, const double* X_dev, const double* y_dev, int64_t N, int D,
+                        const double* Xq_dev, int64_t M, double* lml_out, double* jitter_out, double* mean_dev,
+                        double* var_dev, double min_var) {
+  return fit_predict_common(h, X_dev, y_dev, N, D, Xq_dev, M, lml_out, jitter_out, mean_dev, var_dev, min_var, true);
 }
 
 static int predict_common(bgp_handle* h, const double* Xq, int64_t M, double* mean, double* var,

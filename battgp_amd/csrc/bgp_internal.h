@@ -38,6 +38,8 @@ struct bgp_handle {
   int lookahead = 1;
   // problem
   int64_t N = 0, Npad = 0, lda = 0;
+  int64_t aug_cap = BGP_AUG;   // rows allocated below the matrix: 64 (y block) + room for riding query rows
+  int64_t aug_used = BGP_AUG;  // rows of it that took part in the last factorisation
   int D = 0;
   bool fitted = false;
   bool alpha_ready = false;

@@ -125,6 +125,36 @@ class ExactGPEngine:
         self._check(rc, "bgp_fit_dev")
         return self._after_fit(lml, jit)
 
+    def fit_predict(self, x: np.ndarray, y: np.ndarray, xq: np.ndarray, want_var: bool = True, min_var: float = 1e-10):
+        """Fit and evaluate the posterior at ``xq`` in one pass (the query rows ride through the
+        factorisation).  Returns ``(lml, mean, var)`` (``var`` is None if not wanted)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        xq = np.ascontiguousarray(xq, dtype=np.float64).reshape(-1, x.shape[1])
+        self.n, self.d = x.shape
+        m = xq.shape[0]
+        mean = np.empty(m, dtype=np.float64)
+        var = np.empty(m, dtype=np.float64) if want_var else None
+        lml, jit = C.c_double(), C.c_double()
+        rc = self._lib.bgp_fit_predict(
+            self._h, dptr(x), dptr(y), self.n, self.d, dptr(xq), m, C.byref(lml), C.byref(jit), dptr(mean),
+            dptr(var) if want_var else None, float(min_var),
+        )
+        self._check(rc, "bgp_fit_predict")
+        return self._after_fit(lml, jit), mean, var
+
+    def fit_predict_device(self, x_ptr, y_ptr, n, d, xq_ptr, m, mean_ptr, var_ptr, min_var: float = 1e-10) -> float:
+        self.n, self.d = int(n), int(d)
+        lml, jit = C.c_double(), C.c_double()
+        rc = self._lib.bgp_fit_predict_dev(
+            self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), self.n, self.d, C.c_void_p(xq_ptr), int(m), C.byref(lml),
+            C.byref(jit), C.c_void_p(mean_ptr), C.c_void_p(var_ptr) if var_ptr else None, float(min_var),
+        )
+        self._check(rc, "bgp_fit_predict_dev")
+        return self._after_fit(lml, jit)
+
     def refit(self, hyp) -> float:
         hyp = np.ascontiguousarray(np.asarray(hyp, dtype=np.float64).reshape(-1))
         lml, jit = C.c_double(), C.c_double()

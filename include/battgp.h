@@ -105,6 +105,20 @@ int bgp_fit_dev(bgp_handle* h, const double* X_dev, const double* y_dev, int64_t
  * of the optimiser loops in src/gp/training.py:39-41,126-145. */
 int bgp_refit(bgp_handle* h, const double* hyp, int nhyp, double* lml_out, double* jitter_out);
 
+/* FIT + first PREDICT in one pass: the cross-covariance rows K(Xq, X) are appended below the
+ * matrix (next to the augmented y row) and ride through the factorisation, so V^T = K_*X L^-T comes
+ * out of the Cholesky itself: mean = V^T z, var = k_** - rowsumsq(V^T); no separate triangular
+ * solve of the query block.  This is the reference's actual flow: the model is built lazily and the
+ * first predict() triggers the factorisation (src/batt_models/battcellgp_full.py:171-173,
+ * battgp_full.py:100,109).  The handle stays fitted: later bgp_predict() calls with other queries
+ * use the stored factor.  var_out may be NULL. */
+int bgp_fit_predict(bgp_handle* h, const double* X_host, const double* y_host, int64_t N, int D,
+                    const double* Xq_host, int64_t M, double* lml_out, double* jitter_out, double* mean_out,
+                    double* var_out, double min_var);
+int bgp_fit_predict_dev(bgp_handle* h, const double* X_dev, const double* y_dev, int64_t N, int D,
+                        const double* Xq_dev, int64_t M, double* lml_out, double* jitter_out, double* mean_dev,
+                        double* var_dev, double min_var);
+
 /* Gradient of the LML of the last fit w.r.t. the hyper-parameter vector (same layout as hyp):
  *   d lml / d theta_i = 1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta_i).
  * Sigma^-1 is formed explicitly on the GPU (U = L^-T, then U U^T: 2/3 N^3 flop on the MFMA kernel, two

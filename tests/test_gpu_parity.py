@@ -360,3 +360,46 @@ def test_lml_gradient_production_hyperparameters():
     e.close()
     # entries span 20 orders of magnitude (d/ds_w ~ 1e13): compare each relative to itself
     assert np.allclose(g, g_ref, rtol=1e-5), (g, g_ref)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (65, 300), (700, 37), (2048, 300), (300, 1000)])
+def test_fit_predict_fused_equals_separate(n, m):
+    x, y = synthetic.make_cell_data(n, seed=n + m)
+    xq = synthetic.make_query(x, m)
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    lml_f, mean_f, var_f = e.fit_predict(x, y, xq, min_var=-1.0)
+    # the handle stays fitted: another query set goes through the stored factor
+    xq2 = synthetic.make_query(x, 11, op=(-30.0, 60.0, 20.0))
+    m2, v2 = e.predict(xq2, min_var=-1.0)
+    e.close()
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    lml_s = e.fit(x, y)
+    mean_s, var_s = e.predict(xq, min_var=-1.0)
+    m2s, v2s = e.predict(xq2, min_var=-1.0)
+    e.close()
+    ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
+    m_ref, v_ref = ref.predict(xq, clamp=False)
+    assert abs(lml_f - lml_s) <= 1e-12 * abs(lml_s) and abs(lml_f - ref.lml) <= REL * abs(ref.lml)
+    assert rel_err(mean_f, m_ref) < REL and rel_err(mean_f, mean_s) < 1e-9
+    kd = K.kernel_diag(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, xq)
+    assert np.max(np.abs(var_f - v_ref) / kd) < 1e-9 and np.max(np.abs(var_f - var_s) / kd) < 1e-10
+    assert rel_err(m2, m2s) < 1e-9 and np.max(np.abs(v2 - v2s)) < 1e-10 * synthetic.OUTPUTSCALE_RBF
+
+
+def test_fit_predict_with_jitter_retry():
+    x = np.zeros((3, 2))
+    y = np.ones(3)
+    hyp = np.array([0.0, 1.0, 1.0, 1.0])
+    e = ExactGPEngine(K.KERNEL_BATTGP, hyp)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        lml, mean, var = e.fit_predict(x, y, np.array([[0.0, 0.0], [1.0, 0.5]]), min_var=-1.0)
+    assert e.jitter == 1e-8
+    e.close()
+    ref = OracleGP(K.KERNEL_BATTGP, hyp, x, y)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.fit()
+    m_ref, v_ref = ref.predict(np.array([[0.0, 0.0], [1.0, 0.5]]), clamp=False)
+    assert abs(lml - ref.lml) < 1e-6 * abs(ref.lml)
+    assert np.allclose(mean, m_ref, rtol=1e-6) and np.allclose(var, v_ref, rtol=1e-5, atol=1e-9)
