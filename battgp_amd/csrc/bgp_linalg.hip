@@ -119,15 +119,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
     for (int q = 0; q < NLB; ++q)
       regB[q] = *reinterpret_cast<const double2*>(gB_safe + (koff + q * CSB) * ldb);
   };
-  const double za = a_in ? 1.0 : 0.0;
-  const double zb = b_in ? ((MODE == 0 || MODE == 2) ? -1.0 : 1.0) : 0.0;  // MODE 0/2 stage -B
+  // No zeroing of the clamped out-of-range rows is needed: a garbage row of A (B) only reaches
+  // accumulators of C rows >= m (columns >= n), which the epilogue never writes.
+  // MODE 0/2 need -A B^T: the f64 MFMA negates its A operand when bit 0 of the last immediate is set.
+  constexpr int NEG = (MODE == 0 || MODE == 2) ? 1 : 0;
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NLA; ++q)
-      *reinterpret_cast<double2*>(&sA[buf][ca + q * CSA][ra]) = make_double2(regA[q].x * za, regA[q].y * za);
+      *reinterpret_cast<double2*>(&sA[buf][ca + q * CSA][ra]) = make_double2(regA[q].x, regA[q].y);
 #pragma unroll
     for (int q = 0; q < NLB; ++q)
-      *reinterpret_cast<double2*>(&sB[buf][cb + q * CSB][rb]) = make_double2(regB[q].x * zb, regB[q].y * zb);
+      *reinterpret_cast<double2*>(&sB[buf][cb + q * CSB][rb]) = make_double2(regB[q].x, regB[q].y);
   };
 
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
       for (int a = 0; a < MJ; ++a)
 #pragma unroll
         for (int b = 0; b < MI; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, NEG);
       if (kk == 0 && !(ABL & 1) && !(ABL & 8)) {
         if (decltype(do_store)::value) {
 #pragma unroll

@@ -403,3 +403,4 @@ def test_fit_predict_with_jitter_retry():
     m_ref, v_ref = ref.predict(np.array([[0.0, 0.0], [1.0, 0.5]]), clamp=False)
     assert abs(lml - ref.lml) < 1e-6 * abs(ref.lml)
     assert np.allclose(mean, m_ref, rtol=1e-6) and np.allclose(var, v_ref, rtol=1e-5, atol=1e-9)
+
