@@ -20,49 +20,77 @@ constexpr int BK = 16;  // k-depth of one LDS stage
 // Map a linear block id to a tile.  Tiles are grouped in 8x8 super-tiles and super-tiles are
 // dealt round-robin to the 8 XCDs (block b runs on XCD b % 8 - observed, speed only), so the
 // ~64 workgroups resident on one XCD share 16 operand panels in that XCD's private L2.
+#ifndef BGP_SUPER_LOG_SI
+#define BGP_SUPER_LOG_SI 3  // super-tile = 2^SI x 2^(6-SI) tiles (64 per super-tile); 8 x 8 by default
+#endif
 __device__ __forceinline__ bool map_tile(int64_t b, int nti, int ntj, int lower, int& ti, int& tj) {
-  const int nsi = (nti + 7) >> 3;
-  int nsj = (ntj + 7) >> 3;
-  if (lower && nsj > nsi) nsj = nsi;  // tiles with tj > ti are never needed
+  constexpr int LSI = BGP_SUPER_LOG_SI, LSJ = 6 - BGP_SUPER_LOG_SI;
+  constexpr int SI = 1 << LSI, SJ = 1 << LSJ;
+  const int nsi = (nti + SI - 1) >> LSI;
+  int nsj = (ntj + SJ - 1) >> LSJ;
   const int64_t slot = b >> 3;
   const int xcd = (int)(b & 7);
   const int64_t s = (slot >> 6) * 8 + xcd;
   const int w = (int)(slot & 63);
   int si, sj;
   if (lower) {
-    // valid super pairs: sj <= si, sj < nsj.  First the triangle si < nsj, then full rows.
-    const int64_t ntri = (int64_t)nsj * (nsj + 1) / 2;
-    const int64_t total = ntri + (int64_t)(nsi > nsj ? nsi - nsj : 0) * nsj;
-    if (s >= total) return false;
-    if (s < ntri) {
-      int64_t i = (int64_t)((__builtin_sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
-      while ((i + 1) * (i + 2) / 2 <= s) ++i;
-      while (i * (i + 1) / 2 > s) --i;
-      si = (int)i;
-      sj = (int)(s - i * (i + 1) / 2);
+    // a super-tile (si, sj) is needed iff it contains a tile with ti >= tj:  (si+1) SI - 1 >= sj SJ
+    // rows of super-tiles: row si has min(nsj, ((si+1) SI - 1) / SJ + 1) valid super-tiles
+    auto rowcount = [&](int64_t r) {
+      int64_t c = (((r + 1) << LSI) - 1) / SJ + 1;
+      return c < nsj ? c : (int64_t)nsj;
+    };
+    // linear search over super-tile rows would be O(nsi); use the closed form of the prefix for the
+    // square case (SI == SJ) and a short loop otherwise
+    if (SI == SJ) {
+      if (nsj > nsi) nsj = nsi;
+      const int64_t ntri = (int64_t)nsj * (nsj + 1) / 2;
+      const int64_t total = ntri + (int64_t)(nsi > nsj ? nsi - nsj : 0) * nsj;
+      if (s >= total) return false;
+      if (s < ntri) {
+        int64_t i = (int64_t)((__builtin_sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= s) ++i;
+        while (i * (i + 1) / 2 > s) --i;
+        si = (int)i;
+        sj = (int)(s - i * (i + 1) / 2);
+      } else {
+        const int64_t r = s - ntri;
+        si = nsj + (int)(r / nsj);
+        sj = (int)(r % nsj);
+      }
     } else {
-      const int64_t r = s - ntri;
-      si = nsj + (int)(r / nsj);
-      sj = (int)(r % nsj);
+      int64_t acc = 0, r = 0;
+      for (; r < nsi; ++r) {
+        const int64_t c = rowcount(r);
+        if (s < acc + c) break;
+        acc += c;
+      }
+      if (r >= nsi) return false;
+      si = (int)r;
+      sj = (int)(s - acc);
     }
   } else {
     if (s >= (int64_t)nsi * nsj) return false;
     si = (int)(s % nsi);
     sj = (int)(s / nsi);
   }
-  ti = si * 8 + (w & 7);
-  tj = sj * 8 + (w >> 3);
+  ti = si * SI + (w & (SI - 1));
+  tj = sj * SJ + (w >> LSI);
   if (ti >= nti || tj >= ntj) return false;
   if (lower && ti < tj) return false;
   return true;
 }
 
 __host__ int64_t gemm_grid_blocks(int nti, int ntj, int lower) {
-  const int64_t nsi = (nti + 7) >> 3, nsj = (ntj + 7) >> 3;
-  int64_t total;
+  constexpr int LSI = BGP_SUPER_LOG_SI, LSJ = 6 - BGP_SUPER_LOG_SI;
+  constexpr int SI = 1 << LSI, SJ = 1 << LSJ;
+  const int64_t nsi = (nti + SI - 1) >> LSI, nsj = (ntj + SJ - 1) >> LSJ;
+  int64_t total = 0;
   if (lower) {
-    const int64_t nsjc = nsj < nsi ? nsj : nsi;
-    total = nsjc * (nsjc + 1) / 2 + (nsi > nsjc ? nsi - nsjc : 0) * nsjc;
+    for (int64_t r = 0; r < nsi; ++r) {
+      int64_t c = (((r + 1) << LSI) - 1) / SJ + 1;
+      total += c < nsj ? c : nsj;
+    }
   } else {
     total = nsi * nsj;
   }
