@@ -86,6 +86,21 @@ def target_size_report(n: int, m: int) -> dict:
     for name, kid, hyp in (("battgp", KERNEL_BATTGP, synthetic.HYP_BATTGP), ("matern32", KERNEL_MATERN32, synthetic.HYP_MATERN32)):
         eng = ExactGPEngine(kid, hyp, device=torch.cuda.current_device())
         try:
+            # fill kernel alone, launched back to back on a scratch matrix of the same shape: its steady
+            # rate.  (Inside a fit the fill is the first big kernel after a host-side gap and pays ~2 ms of
+            # clock ramp-up - tools/fill_hot_probe.py - which is reported separately as fill_gbs.)
+            ld = n + 384
+            scratch = torch.empty((n, ld), dtype=torch.float64, device="cuda")
+            tx = torch.from_numpy(x).cuda()
+            torch.cuda.synchronize()
+            rates = []
+            for _ in range(4):
+                eng.fill_device(tx.data_ptr(), n, tx.data_ptr(), n, 4, scratch.data_ptr(), ld, lower=1, diag_add=float(hyp[0]))
+                ph = eng.phase_times()
+                rates.append(ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9)
+            del scratch, tx
+            torch.cuda.empty_cache()
+            fill_steady = float(np.median(rates[1:]))
             eng.fit_predict(x, y, xq)  # first pass from an idle, down-clocked GPU: warm-up only
             t0 = time.perf_counter()
             eng.fit_predict(x, y, xq)  # fill + factorisation with the query rows riding + posterior
@@ -96,6 +111,8 @@ def target_size_report(n: int, m: int) -> dict:
                 "fit_predict_s": wall,
                 "fill_gbs": ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9,
                 "fill_frac_hbm": ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "fill_steady_gbs": fill_steady,
+                "fill_steady_frac_hbm": fill_steady / PEAK_HBM_GBS,
                 "potrf_tflops": (n**3 / 3.0) / (ph["potrf_ms"] * 1e-3) / 1e12,
                 "trail_tflops": ph["trail_flop"] / (ph["trail_ms"] * 1e-3) / 1e12,
                 "trail_frac_mfma": ph["trail_flop"] / (ph["trail_ms"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,

@@ -37,8 +37,8 @@ cal2_calls, cal2_fetch = pick(fetch, "gemv_t_partial_kernel")
 l_bytes = 4.0 * n * n  # lower triangle read once
 fetch_factor = 2.0
 fill_calls, fill_write = pick(write, "fill_kernel")
-gemm_calls, gemm_fetch = pick(fetch, "gemm_nt_kernel<128, 128, 0")
-_, gemm_write = pick(write, "gemm_nt_kernel<128, 128, 0")
+gemm_calls, gemm_fetch = pick(fetch, "gemm_nt_kernel<128, 128, ")
+_, gemm_write = pick(write, "gemm_nt_kernel<128, 128, ")
 out = {
     "source": src,
     "workload": f"bench.py --n {n} --steps 1 --warmup 0 (one fit + predict, K0)",
