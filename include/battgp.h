@@ -54,9 +54,9 @@ enum {
   BGP_T_H2D = 0,      /* host->device upload of X, y                    */
   BGP_T_FILL = 1,     /* covariance fill  K + (noise+jitter) I           */
   BGP_T_POTRF = 2,    /* blocked Cholesky (all attempts of the ladder)   */
-  BGP_T_SOLVE = 3,    /* z = L^-1 y, alpha = L^-T z, log det, y^T alpha  */
-  BGP_T_CROSS = 4,    /* cross-covariance fill + posterior mean          */
-  BGP_T_VAR = 5,      /* V = L^-1 K_X*, predictive variance              */
+  BGP_T_SOLVE = 3,    /* z gather + log det + z^T z; lazy alpha = L^-T z; or the gradient pass */
+  BGP_T_CROSS = 4,    /* cross-covariance fill (+ mean for mean-only predictions) */
+  BGP_T_VAR = 5,      /* V^T = K_*X L^-T pass (if not fused), mean = V^T z, variance */
   BGP_T_D2H = 6,      /* device->host of results                         */
   BGP_T_TRAIL = 7,    /* sum of the outer trailing-update (MFMA SYRK) launches of the last potrf */
   BGP_T_TRAIL_FLOP = 8, /* algorithmic flop of those launches (2*m*n*k per full tile pair, lower half) */
