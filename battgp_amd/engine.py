@@ -171,6 +171,8 @@ class ExactGPEngine:
 
     def predict(self, xq: np.ndarray, want_var: bool = True, min_var: float = 1e-10):
         xq = np.ascontiguousarray(xq, dtype=np.float64)
+        if self.d == 0:
+            raise EngineError("bgp_predict: no successful fit on this handle")
         if xq.ndim == 1:
             xq = xq.reshape(-1, self.d)
         if xq.shape[1] != self.d:

@@ -404,3 +404,58 @@ def test_fit_predict_with_jitter_retry():
     assert abs(lml - ref.lml) < 1e-6 * abs(ref.lml)
     assert np.allclose(mean, m_ref, rtol=1e-6) and np.allclose(var, v_ref, rtol=1e-5, atol=1e-9)
 
+
+
+@pytest.mark.parametrize("d", [2, 3, 6])
+def test_fit_predict_generic_input_dimension(d):
+    """The reference's kernel builder takes any number of RBF dims (tests/gp/test_spatiotemporal_gp.py:18-39);
+    D = 4 has a specialised fill kernel, every other D goes through the generic one."""
+    rng = np.random.default_rng(d)
+    n = 333
+    x = np.column_stack([np.sort(rng.uniform(0, 9, n))] + [rng.normal(size=n) for _ in range(d - 1)])
+    y = np.sin(x[:, 0]) + 0.1 * rng.normal(size=n)
+    xq = np.column_stack([rng.uniform(0, 9, 40)] + [rng.normal(size=40) for _ in range(d - 1)])
+    hyp = np.array([0.1, 10.0, 3.0] + [2.0 + 0.3 * i for i in range(d - 1)])
+    _check_case(K.KERNEL_BATTGP, hyp, x, y, xq)
+    if d == 3:
+        _check_case(K.KERNEL_MATERN32, np.array([0.05, 1.5, 2.0, 1.0, 3.0]), x, y, xq)
+        _check_case(K.KERNEL_SCALED_RBF, np.array([0.05, 1.5, 2.0]), x[:, :1], y, xq[:, :1])
+
+
+def test_errors_are_reported_not_crashed():
+    from battgp_amd.engine import EngineError
+
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    x, y = synthetic.make_cell_data(100)
+    with pytest.raises(EngineError, match="no successful fit"):
+        e.predict(x[:3])
+    with pytest.raises(EngineError, match="expects 6 hyper-parameters|hyper-parameters"):
+        e.fit(x[:, :3], y)  # D = 3 with a 6-entry hyp vector
+    with pytest.raises(EngineError, match="not a positive finite"):
+        e.set_hyp([1e-6, -1.0, 1.0, 1.0, 1.0, 1.0])
+    with pytest.raises(EngineError, match="nb_outer"):
+        e.set_options(nb_outer=100)
+    # NaN in the targets is harmless for the factorisation; NaN in the inputs poisons Sigma -> NotPSD
+    e.set_hyp(synthetic.HYP_BATTGP)
+    xb = x.copy()
+    xb[7, 2] = np.nan
+    with pytest.raises(NotPSDError):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            e.fit(xb, y)
+    e.fit(x, y)  # the handle is still usable afterwards
+    assert np.isfinite(e.lml)
+    e.close()
+
+
+def test_allocation_failure_is_an_error_message():
+    from battgp_amd.engine import EngineError
+
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    n = 400_000  # 1.28 TB: cannot fit
+    x = np.zeros((n, 4))
+    with pytest.raises(EngineError, match="hipMalloc"):
+        e.fit(x, np.zeros(n))
+    x, y = synthetic.make_cell_data(200)
+    assert np.isfinite(e.fit(x, y))
+    e.close()

@@ -36,6 +36,21 @@ static void run_lower(const char* name, double* C, double* A, int64_t ld, int64_
   printf("%-44s k=%4d  %8.3f ms  %6.2f TFLOP/s (m=%lld lower, super 2^%d)\n", name, k, best, (double)m * (m + 1) * k / best / 1e9, (long long)m, BGP_SUPER_LOG_SI);
 }
 
+template <int TN>
+static void run_tn(const char* name, double* C, double* A, int64_t ld, int64_t m, int64_t n, int k) {
+  const int nti = (int)((m + 127) / 128), ntj = (int)((n + TN - 1) / TN);
+  const int64_t blocks = gemm_grid_blocks(nti, ntj, 0);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((gemm_nt_kernel<128, TN, 2, 0>), dim3((unsigned)blocks), dim3(256), 0, 0, C, ld, A, ld, A, ld, m, n, k, 0, nti, ntj, (const int*)nullptr);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+  }
+  printf("%-44s k=%4d  %8.3f ms  %6.2f TFLOP/s\n", name, k, best, 2.0 * m * n * k / best / 1e9);
+}
+
 int main() {
   const int64_t m = 16384, n = 16384, ld = m + 64;
   double *A, *C;
@@ -45,9 +60,11 @@ int main() {
   { std::vector<double> hbuf(ld * 2048); unsigned long long s = 88172645463325252ull; for (auto& v : hbuf) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; } hipMemcpy(A, hbuf.data(), hbuf.size() * 8, hipMemcpyHostToDevice); }
   run_lower("atomic SYRK lower", C, A, ld, 16384, 512);
   run_lower("atomic SYRK lower", C, A, ld, 16384, 512);
-  for (int k : {512}) {
+  for (int k : {256, 512, 1024}) {
     run<0>("production (staging interleaved 1/MFMA)", C, A, ld, m, n, k);
     run<0, 0, 2>("atomic-add epilogue (no C read)", C, A, ld, m, n, k);
+    run_tn<128>("atomic, tile 128x128 (2 WG/CU)", C, A, ld, m, n, k);
+    run_tn<64>("atomic, tile 128x64 (3 WG/CU by LDS)", C, A, ld, m, n, k);
     run<1>("no re-staging (no global loads/ds_write)", C, A, ld, m, n, k);
     run<3>("no re-staging, no barriers", C, A, ld, m, n, k);
     run<2>("staging but no barriers (racy, timing only)", C, A, ld, m, n, k);
