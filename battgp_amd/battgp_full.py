@@ -1,0 +1,204 @@
+"""System-level ``full_gp`` driver: one pack model + one model per cell, all predicted on a common
+300-point time grid at the reference operating point, merged into one data frame and saved as
+feather + json.  Same public behaviour as the reference's ``BattGP_Full`` / ``BattGP`` / ``BattGPResult``
+(``src/batt_models/battgp_full.py:15-125``, ``src/batt_models/battgp.py:16-262``) - so the
+``gp_runner.py`` ``full_gp`` branch (``:68-96``) and ``calc_fault_probabilities`` consume it unchanged -
+with two MI355X-native additions: ``devices=`` spreads the (independent) GPs over several GPUs, one
+GP per GPU at a time, and models are freed right after use because one N x N fp64 factor fills a card.
+"""
+
+from __future__ import annotations
+
+import gc
+import json
+import os
+from dataclasses import dataclass
+from typing import Any, Dict, Iterable, List, Literal, Optional, Union
+
+import numpy as np
+import pandas as pd
+
+from .battcellgp_full import BatteryCellGP_Full, build_cellmodel_full
+from .operating_point import Op, get_causal_tag, get_cell_tag
+
+
+@dataclass
+class BattGPResult:
+    """``src/batt_models/battgp.py:16-92``."""
+
+    batt_data: Any
+    cellmodels: List[BatteryCellGP_Full]
+    ref_op: Op
+    df: pd.DataFrame
+
+    def get_cell_data(
+        self,
+        cellnrs: Union[Iterable[int], int],
+        signals: Optional[Iterable[str]] = None,
+        causal: bool = False,
+        missing_behaviour: Literal["error", "ignore"] = "error",
+    ) -> pd.DataFrame:
+        per_cell = ("r0", "r0var", "dr0", "dr0var")
+        if signals is None:
+            signals = ["t", "ds_count", "r0", "r0var", "dr0", "dr0var"]
+        single = isinstance(cellnrs, (int, np.integer))
+        cells = [int(cellnrs)] if single else list(cellnrs)
+        ctag = get_causal_tag(causal)
+        wanted: list[str] = []
+        rename: dict[str, str] = {}
+        for sig in signals:
+            if sig not in per_cell:
+                wanted.append(sig)
+                rename[sig] = sig
+                continue
+            for c in cells:
+                src = f"{sig}_{ctag}_{get_cell_tag(c)}"
+                wanted.append(src)
+                rename[src] = sig if single else f"{sig}_{get_cell_tag(c)}"
+        present = [w for w in wanted if w in self.df.columns]
+        if len(present) < len(wanted) and missing_behaviour == "error":
+            missing = sorted(set(wanted) - set(present))
+            raise ValueError(f"signal(s) {', '.join(missing)} not available in the result")
+        return self.df[present].rename(columns=rename)
+
+
+class BattGP_Full:
+    def __init__(
+        self,
+        batt_data,
+        *,
+        max_training_data: Optional[int] = None,
+        max_age: Optional[int] = None,
+        ref_op: Optional[Op] = None,
+        ref_strategy: str = "mean",
+        device=None,
+        devices: Optional[list] = None,
+        save_path: Optional[str] = None,
+        **kwargs,
+    ) -> None:
+        if max_training_data is None:
+            max_training_data = 2000  # battgp_full.py:27-31
+            print(f"Max training data set to {max_training_data}, because no values was passed for max_training_data")
+        self.batt_data = batt_data
+        self.max_training_data = max_training_data
+        self.max_age = batt_data.age if max_age is None else max_age
+        if ref_op is not None:
+            self.ref_op = ref_op
+        elif ref_strategy == "median":
+            self.ref_op = batt_data.median_op
+        else:
+            self.ref_op = batt_data.mean_op
+        self.save_path = None
+        if save_path is not None:
+            self.save_path = os.path.join(save_path, batt_data.id)
+            os.makedirs(self.save_path, exist_ok=True)
+        # one device for everything (the reference), or a list to deal the 1 + n_cells GPs over
+        self.devices = list(devices) if devices else [device]
+        cells = [-1] + list(batt_data.cell_nrs)
+        models = [
+            build_cellmodel_full(
+                c, batt_data, max_training_data=max_training_data, max_age=self.max_age, device=self.devices[i % len(self.devices)], **kwargs
+            )
+            for i, c in enumerate(cells)
+        ]
+        self.packmodel: BatteryCellGP_Full = models[0]
+        self.cellmodels: List[BatteryCellGP_Full] = models[1:]
+        self.t = None
+
+    # -- small accessors of the base class (battgp.py:131-179) -------------------------------------
+    def set_operating_point(self, op: Op, verbose: bool = True) -> None:
+        if verbose:
+            print(f"Battery operating point set to: {op.disp_str()}")
+        self.ref_op = op
+
+    def get_operating_point(self) -> Op:
+        return self.ref_op
+
+    def get_cell_model(self, cellnr: int) -> BatteryCellGP_Full:
+        if cellnr == -1:
+            return self.packmodel
+        for cell in self.cellmodels:
+            if cell.cellnr == cellnr:
+                return cell
+        raise ValueError(f"cell {cellnr} does not exist")
+
+    def get_parameters(self) -> Dict[str, Any]:
+        return {  # battgp_full.py:62-68
+            "ref_point": self.get_operating_point().disp_str(),
+            "segment_criteria": "Saving segment criteria not implemented yet, see config.py",
+            "gap_removal": "Saving gap removal not implemented yet, see config.py",
+            "ocv_path": "Saving ocv path not implemented yet, see config.py",
+        }
+
+    # -- hyper-parameters (battgp.py:181-231) -------------------------------------------------------
+    def train_hyperparameters(self, parallelize: bool = False, messages: bool = True) -> None:
+        models = [self.packmodel, *self.cellmodels]
+        if not parallelize:
+            for mdl in models:
+                mdl.train_hyperparameters(messages=messages)
+            return
+        # one thread per model (handles are independent; the C-ABI calls release the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(len(models)) as pool:
+            list(pool.map(lambda mdl: mdl.train_hyperparameters(messages=False), models))
+
+    def save_hyperparameters(self, path: str) -> None:
+        save_path = os.path.join(path, self.batt_data.id)
+        os.makedirs(save_path, exist_ok=True)
+        for mdl in [self.packmodel, *self.cellmodels]:
+            mdl.save_hyperparameters(save_path)
+
+    # -- the hot call (battgp_full.py:70-125) -------------------------------------------------------
+    def _time_grid(self, add_time_steps: bool) -> np.ndarray:
+        t_train = self.cellmodels[0].model.train_inputs[0][:, 0].detach().cpu().numpy()
+        if add_time_steps:
+            extra = np.linspace(t_train[0], self.batt_data.age, int(self.batt_data.age - t_train[0]))
+            return np.sort(np.concatenate((t_train, extra)))
+        return np.linspace(t_train[0], self.batt_data.age, 300)
+
+    @staticmethod
+    def _free(model: BatteryCellGP_Full) -> None:
+        del model.model  # releases the engine handle and its HBM
+        gc.collect()
+
+    def predict_cell_r0_op(self, destroy_after_run: bool = True, add_time_steps: bool = False, save: bool = True) -> BattGPResult:
+        self.t = self._time_grid(add_time_steps)
+        models = [self.packmodel, *self.cellmodels]
+        frames: list[Optional[pd.DataFrame]] = [None] * len(models)
+        keep = len(models) - 1  # the last cell model stays alive for the plots (plotting.py:233,259)
+
+        def run(idxs):
+            for i in idxs:
+                frames[i] = models[i].predict_r0_op(op=self.ref_op, t=self.t)
+                if destroy_after_run and i != keep:
+                    self._free(models[i])
+
+        if len(self.devices) == 1:
+            run(range(len(models)))
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+
+            groups = [[i for i in range(len(models)) if i % len(self.devices) == d] for d in range(len(self.devices))]
+            with ThreadPoolExecutor(len(groups)) as pool:
+                list(pool.map(run, groups))
+        df = frames[0]
+        for f in frames[1:]:
+            df = df.merge(f)
+        if save and self.save_path is not None:
+            self.save_df(df)
+        return BattGPResult(self.batt_data, self.cellmodels, self.ref_op, df)
+
+    def save_df(self, df: Optional[pd.DataFrame]) -> None:
+        """feather + json pair, data file removed first so the two never disagree (battgp.py:233-262)."""
+        f_data = os.path.join(self.save_path, "battgpf_df.feather")
+        f_info = os.path.join(self.save_path, "battgpf_info.json")
+        if df is not None:
+            for f in (f_data, f_info):
+                try:
+                    os.remove(f)
+                except FileNotFoundError:
+                    pass
+            df.to_feather(f_data)
+        with open(f_info, "w") as fil:
+            json.dump(self.get_parameters(), fil)

@@ -60,3 +60,28 @@ def make_query(x: np.ndarray, m: int = N_QUERY, op=REF_OP) -> np.ndarray:
 def standardise(x: np.ndarray) -> np.ndarray:
     """Zero-mean/unit-variance columns, for the isotropic ``ScaledRBFModel`` runs."""
     return (x - x.mean(axis=0)) / x.std(axis=0)
+
+
+class SyntheticBattData:
+    """Stand-in for the reference's ``BattData`` with only the contract the ``full_gp`` drivers use
+    (``src/batt_data/batt_data.py``): ``id``, ``age``, ``cell_nrs``, ``mean_op`` / ``median_op`` and
+    ``generateTrainingData(cellnr, max_training_data, max_age) -> (X[N,4], y[N])``.  Every cell gets its
+    own current / temperature / resistance realisation (cell -1 is the pack model), like the per-cell
+    sensors of the field data; the data set itself is not available offline."""
+
+    def __init__(self, batt_id: str = "synthetic", n_cells: int = 8, age_days: float = 1200.0, seed: int = 0):
+        from .operating_point import Op
+
+        self.id = batt_id
+        self.age = age_days
+        self.cell_nrs = list(range(1, n_cells + 1))
+        self.seed = seed
+        self.mean_op = Op(*REF_OP)
+        self.median_op = Op(*REF_OP)
+
+    def generateTrainingData(self, cellnr: int, max_training_data: int, max_age=None):
+        age = self.age if max_age is None else min(self.age, max_age)
+        x, y = make_cell_data(max_training_data, seed=self.seed * 1000 + 17 * (cellnr + 2), age_days=age)
+        # cells age slightly differently: a per-cell offset and slope on top of the common trend
+        y = y + 2e-4 * ((cellnr * 7919) % 13 - 6) / 6.0 + 2e-7 * ((cellnr * 104729) % 11) * x[:, 0]
+        return x, y

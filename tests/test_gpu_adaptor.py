@@ -190,3 +190,65 @@ def test_analytic_raw_gradient_matches_finite_differences():
     f_fd, g_fd = training._loss_and_grad_fd(cell.model, raw, rel_step=1e-5)
     assert f == pytest.approx(f_fd, rel=1e-12)
     assert np.allclose(g, g_fd, rtol=2e-4, atol=1e-8 * np.abs(g_fd).max()), (g, g_fd)
+
+
+def test_system_driver_end_to_end(tmp_path):
+    """BattGP_Full on a synthetic 3-cell system: the gp_runner full_gp call sequence
+    (gp_runner.py:68-96), result frame layout, feather/json artefacts, get_cell_data."""
+    import json
+
+    import pandas as pd
+
+    from battgp_amd.battgp_full import BattGP_Full
+    from battgp_amd.synthetic import SyntheticBattData
+
+    try:  # feather needs pyarrow; it is in the image, but do not let a box without it fail the parity part
+        import pyarrow  # noqa: F401
+
+        have_arrow = True
+    except ImportError:
+        have_arrow = False
+    bd = SyntheticBattData("sys7", n_cells=3, seed=7)
+    sysm = BattGP_Full(bd, max_training_data=500, device=0, save_path=str(tmp_path))
+    res = sysm.predict_cell_r0_op(save=have_arrow)
+    df = res.df
+    assert df.shape == (300, 1 + 2 * 4)
+    assert list(df.columns)[:3] == ["t", "r0_acausal_pack", "r0var_acausal_pack"]
+    assert np.isfinite(df.to_numpy()).all() and (df.filter(like="r0var").to_numpy() >= 1e-10).all()
+    # every cell column equals an oracle GP on that cell's data
+    x, y = bd.generateTrainingData(2, 500)
+    xq = np.column_stack((df["t"], np.full(300, res.ref_op.I), np.full(300, res.ref_op.SOC), np.full(300, res.ref_op.T)))
+    m_ref, _ = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit().predict(xq)
+    assert np.linalg.norm(df["r0_acausal_c2"] - m_ref) < 1e-6 * np.linalg.norm(m_ref)
+    # artefacts (battgp.py:233-262)
+    if have_arrow:
+        saved = pd.read_feather(tmp_path / "sys7" / "battgpf_df.feather")
+        assert saved.equals(df)
+        info = json.load(open(tmp_path / "sys7" / "battgpf_info.json"))
+        assert info["ref_point"] == res.ref_op.disp_str()
+    # BattGPResult.get_cell_data naming rules (battgp.py:23-92)
+    one = res.get_cell_data(2, ["t", "r0", "r0var"])
+    assert list(one.columns) == ["t", "r0", "r0var"]
+    many = res.get_cell_data([1, 2, 3], ["t", "r0", "r0var"])
+    assert list(many.columns) == ["t", "r0_c1", "r0_c2", "r0_c3", "r0var_c1", "r0var_c2", "r0var_c3"]
+    with pytest.raises(ValueError, match="not available"):
+        res.get_cell_data(1, ["dr0"])
+    assert res.get_cell_data(1, ["t", "dr0"], missing_behaviour="ignore").shape[1] == 1
+    # all models but the last were destroyed (battgp_full.py:102-120)
+    assert not hasattr(sysm.packmodel, "model") and not hasattr(sysm.cellmodels[0], "model")
+    assert hasattr(sysm.cellmodels[-1], "model")
+    assert sysm.get_cell_model(-1) is sysm.packmodel and sysm.get_cell_model(3).cellnr == 3
+
+
+def test_system_driver_add_time_steps_large_m():
+    """add_time_steps=True (battgp_full.py:86-96): M = N + age query points ride through the factorisation."""
+    from battgp_amd.battgp_full import BattGP_Full
+    from battgp_amd.synthetic import SyntheticBattData
+
+    bd = SyntheticBattData("sys1", n_cells=1, age_days=400.0)
+    sysm = BattGP_Full(bd, max_training_data=300, device=0)
+    res = sysm.predict_cell_r0_op(add_time_steps=True, save=False)
+    # t = 0 is both a training time and the start of the day grid: pandas' merge on "t" duplicates it,
+    # exactly as in the reference (battgp_full.py:86-96,112)
+    assert res.df["t"].nunique() == 300 + 400 - 1 and np.all(np.diff(res.df["t"]) >= 0)
+    assert np.isfinite(res.df.to_numpy()).all()
