@@ -69,6 +69,7 @@ SIGNATURES = {
     ),
     "bgp_diag_logsum_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
     "bgp_rowdot_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bgp_var_finish_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double, C.c_void_p]),
     "bgp_sync": (C.c_int, [handle_p]),
 }
 

@@ -987,6 +987,15 @@ int bgp_rowdot_dev(bgp_handle* h, const double* E_dev, int64_t lde, int64_t M, i
   return launch_rowdot_finish(h, h->s_main, h->dpart, nch, M, nullptr, &p, -1.0, out_dev);
 }
 
+int bgp_var_finish_dev(bgp_handle* h, const double* Xq_dev, int64_t M, int D, const double* ssq_dev, double min_var,
+                       double* out_dev) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  FillParams p;
+  if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
+  return launch_rowdot_finish(h, h->s_main, ssq_dev, 1, M, Xq_dev, &p, min_var, out_dev);
+}
+
 int bgp_sync(bgp_handle* h) {
   int rc = check_handle(h);
   if (rc) return rc;

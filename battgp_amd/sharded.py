@@ -173,6 +173,19 @@ class DeviceBackend:
             "bgp_gemm_nt_sub_async_dev",
         )
 
+    def sumsq(self, v, n) -> float:
+        """sum of squares of a vector, on the device (a 1 x n row block through the row-dot kernel)"""
+        out = self.zeros(1)
+        self._chk(self.lib.bgp_rowdot_dev(self.h, self._p(v), 1, 1, int(n), None, self._p(out)), "bgp_rowdot_dev")
+        self.sync()
+        return float(out[0])
+
+    def var_finish(self, xq_dev, m, d, ssq, min_var):
+        out = self.empty(m)
+        self._chk(self.lib.bgp_var_finish_dev(self.h, self._p(xq_dev), m, d, self._p(ssq), float(min_var), self._p(out)), "bgp_var_finish_dev")
+        self.sync()
+        return out
+
     def rowdot(self, e, lde, m, n, vec, out):
         self._chk(self.lib.bgp_rowdot_dev(self.h, self._p(e), lde, m, n, self._p(vec) if vec is not None else None, self._p(out)), "bgp_rowdot_dev")
 
@@ -255,7 +268,7 @@ class ShardedExactGP:
         self._allreduce(z)
         self._allreduce(ld_t)
         self.z = z
-        zz = float((z * z).sum()) if hasattr(z, "sum") else float(np.dot(z, z))
+        zz = be.sumsq(z, lay.npad)
         self.lml = -0.5 * zz - float(ld_t[0]) - 0.5 * n * math.log(2.0 * math.pi)
         return self.lml
 
@@ -282,9 +295,8 @@ class ShardedExactGP:
         return 0
 
     # ---- predict ----------------------------------------------------------------------------------
-    def predict(self, xq: np.ndarray, min_var: float = 1e-10, kdiag=None):
-        """(mean, var) of the latent f at xq, identical on every rank.  ``kdiag`` = prior variances
-        ``k(xq, xq)`` (host array) - supplied by the caller because it depends on the kernel."""
+    def predict(self, xq: np.ndarray, min_var: float = 1e-10):
+        """(mean, var) of the latent f at xq, identical on every rank."""
         lay, be, ld = self.lay, self.be, self.lay.nrows
         xq = np.ascontiguousarray(xq, dtype=np.float64)
         m = xq.shape[0]
@@ -321,24 +333,8 @@ class ShardedExactGP:
         self._allreduce(mean_p)
         self._allreduce(var_p)
         mean = be.to_host(mean_p)[:m]
-        ssq = be.to_host(var_p)[:m]
-        if kdiag is None:
-            return mean, ssq
-        var = np.asarray(kdiag, dtype=np.float64) - ssq
-        if min_var >= 0:
-            var = np.maximum(var, min_var)
+        var = be.to_host(be.var_finish(xq_dev, m, self.d, var_p, min_var))[:m]
         return mean, var
-
-
-def kernel_diag_host(kernel_id: int, hyp, xq: np.ndarray) -> np.ndarray:
-    """Prior variance k(x, x) on the host (O(M)): ``s_w t^3/3 + s_r`` for the battgp kernel
-    (``diag`` branch of src/gp/wiener_kernel.py:15-16), ``s`` otherwise."""
-    hyp = np.asarray(hyp, dtype=np.float64)
-    xq = np.asarray(xq, dtype=np.float64)
-    if kernel_id == 0:
-        t = xq[:, 0]
-        return hyp[1] * (t * t * t / 3.0) + hyp[2]
-    return np.full(xq.shape[0], hyp[1])
 
 
 def make_sharded_gp(kernel_id: int, hyp, nb: int = 512, backend_name: str | None = None):

@@ -220,6 +220,12 @@ int bgp_diag_logsum_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t 
 int bgp_rowdot_dev(bgp_handle* h, const double* E_dev, int64_t lde, int64_t M, int64_t n, const double* vec_dev,
                    double* out_dev);
 
+/* out_dev[m] = max(k(xq_m, xq_m) - ssq_dev[m], min_var) (no floor if min_var < 0): predictive variance from
+ * the row sums of squares of V^T, with the prior variance of the handle's kernel
+ * (K0: s_w t^3/3 + s_r, the diag branch of src/gp/wiener_kernel.py:15-16). */
+int bgp_var_finish_dev(bgp_handle* h, const double* Xq_dev, int64_t M, int D, const double* ssq_dev, double min_var,
+                       double* out_dev);
+
 /* Wait for everything enqueued on the handle's streams. */
 int bgp_sync(bgp_handle* h);
 

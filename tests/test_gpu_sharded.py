@@ -11,7 +11,7 @@ torch = pytest.importorskip("torch")
 
 from battgp_amd import synthetic  # noqa: E402
 from battgp_amd.engine import ExactGPEngine  # noqa: E402
-from battgp_amd.sharded import make_sharded_gp, kernel_diag_host  # noqa: E402
+from battgp_amd.sharded import make_sharded_gp  # noqa: E402
 from oracle import kernels as K  # noqa: E402
 from oracle.exact_gp import OracleGP  # noqa: E402
 
@@ -22,7 +22,7 @@ def test_sharded_single_rank_matches_oracle_and_engine(n, nb):
     xq = synthetic.make_query(x, 57)
     gp = make_sharded_gp(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, nb=nb)
     lml = gp.fit(x, y)
-    mean, var = gp.predict(xq, kdiag=kernel_diag_host(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, xq))
+    mean, var = gp.predict(xq)
     ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
     m_ref, v_ref = ref.predict(xq)
     assert gp.jitter == 0.0
@@ -59,13 +59,13 @@ def _two_rank_worker(rank, world, port, n, nb, q):
     # on one device) - the schedule, packing and offsets are exactly those of the multi-GPU run
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from battgp_amd import parallel, synthetic
-    from battgp_amd.sharded import kernel_diag_host, make_sharded_gp
+    from battgp_amd.sharded import make_sharded_gp
 
     x, y = synthetic.make_cell_data(n, seed=9)
     xq = synthetic.make_query(x, 33)
     gp = make_sharded_gp(0, synthetic.HYP_BATTGP, nb=nb, backend_name="gloo")
     lml = gp.fit(x, y)
-    mean, var = gp.predict(xq, kdiag=kernel_diag_host(0, synthetic.HYP_BATTGP, xq))
+    mean, var = gp.predict(xq)
     q.put((rank, lml, mean.tolist(), var.tolist()))
     parallel.barrier(gp.dist)
     gp.engine.close()

@@ -97,6 +97,13 @@ class NumpyBackend:
         l21 = self._cm(store, lcol0 * ld + row0, nrows, nbk, ld)
         self._cm(w, wcol0 * lde, me, nrows, lde)[:] -= self._cm(ek, 0, me, nbk, ldek) @ l21.T
 
+    def sumsq(self, v, n):
+        return float(np.dot(v[:n], v[:n]))
+
+    def var_finish(self, xq, m, d, ssq, min_var):
+        var = self.K.kernel_diag(self.kid, self.hyp, xq) - ssq[:m]
+        return np.maximum(var, min_var) if min_var >= 0 else var
+
     def rowdot(self, e, lde, m, n, vec, out):
         em = self._cm(e, 0, m, n, lde)
         out[:m] = em @ vec if vec is not None else np.einsum("ij,ij->i", em, em)
@@ -115,7 +122,7 @@ def _worker(rank, world, port, n, nb, q):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from battgp_amd import parallel, synthetic
-    from battgp_amd.sharded import ShardedExactGP, kernel_diag_host
+    from battgp_amd.sharded import ShardedExactGP
     from test_sharded_cpu import NumpyBackend
 
     dist = parallel.init("gloo") if world > 1 else None
@@ -123,7 +130,7 @@ def _worker(rank, world, port, n, nb, q):
     xq = synthetic.make_query(x, 21)
     gp = ShardedExactGP(NumpyBackend(0, synthetic.HYP_BATTGP), dist, rank, world, nb=nb)
     lml = gp.fit(x, y)
-    mean, var = gp.predict(xq, kdiag=kernel_diag_host(0, synthetic.HYP_BATTGP, xq))
+    mean, var = gp.predict(xq)
     q.put((rank, lml, mean.tolist(), var.tolist()))
     if dist is not None:
         parallel.barrier(dist)
