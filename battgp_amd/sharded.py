@@ -84,13 +84,19 @@ class DeviceBackend:
         self.eng._check(rc, what)
 
     def zeros(self, n):
-        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+        # the fill runs on torch's stream, the engine's kernels on their own: finish it before handing
+        # the buffer to the engine
+        t = self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+        self.after_comm()
+        return t
 
     def empty(self, n):
         return self.torch.empty(int(n), dtype=self.torch.float64, device=self.device)
 
     def upload(self, a):
-        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+        t = self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+        self.after_comm()
+        return t
 
     def to_host(self, t):
         return t.detach().cpu().numpy()
