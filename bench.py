@@ -61,14 +61,15 @@ def cpu_baseline(kernel_id, hyp, n_cpu: int, m: int, seed: int):
     }
 
 
-def traffic_from_profile(n: int, kernel: str):
-    """HBM bytes per dispatch of the MFMA gemm class from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x 2 + WRITE_SIZE, calibration in profiles/*_summary.json); None for other workloads."""
+def traffic_from_profile(n: int, kernel: str, key: str = "hbm_bytes_per_dispatch"):
+    """Per-dispatch HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) or PMC MFMA utilisation of the trailing-update
+    kernel from the committed rocprofv3 passes (tools/profile_round.sh -> profiles/*_summary.json, which
+    holds the calibration); None for workloads that were not profiled."""
     path = os.path.join(ROOT, "profiles", f"r01_n{n}_summary.json")
     if kernel != "battgp" or not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)["gemm_nt_128x128"]["hbm_bytes_per_dispatch"]
+        return json.load(f)["gemm_nt_128x128"].get(key)
 
 
 def target_size_report(n: int, m: int) -> dict:
@@ -245,14 +246,19 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "gemm_nt_kernel<128,128,0> (rank-NB SYRK trailing update of the blocked Cholesky)",
+                "kernel": "gemm_nt_kernel<128,128,2> (rank-NB SYRK trailing update of the blocked Cholesky)",
                 "achieved": trail_tflops,
                 "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": trail_tflops / PEAK_FP64_MFMA_TFLOPS,
                 "traffic": traffic_from_profile(n, args.kernel),
                 "launches_per_step": None,
-                "note": "sum of algorithmic flop m(m+1)k of the outer trailing updates / sum of their HIP-event durations",
+                "mfma_util_pmc": traffic_from_profile(n, args.kernel, "mfma_util"),
+                "note": "sum of algorithmic flop m(m+1)k of the outer trailing updates / sum of their HIP-event durations "
+                        "(= flop per launch / average launch duration); with look-ahead the la and rest launches of a panel "
+                        "overlap each other and the next panel's factorisation, so this under-states the kernel: "
+                        "mfma_util_pmc is SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) of the same kernel "
+                        "from the serialised counter pass in profiles/",
             },
             "roofline_fill": {
                 "bound": "hbm",
