@@ -14,6 +14,8 @@ import shutil
 import sys
 
 src, tag, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+kname = sys.argv[4] if len(sys.argv) > 4 else "battgp"
+suffix = "" if kname == "battgp" else "_" + kname
 m, nb, simds, xccs = 300, 512, 1024, 8
 
 
@@ -70,7 +72,7 @@ tr["algorithmic_flop"] = sum((npad - k1) * (npad - k1 + 1.0) * nb for k1 in rang
 
 out = {
     "source": src,
-    "workload": f"tools/profile_workload.py {n}: one fused fit+predict (K0, M = {m}) + alpha()",
+    "workload": f"tools/profile_workload.py {n}: one fused fit+predict ({kname}, M = {m}) + alpha()",
     "calibration": {
         "fetch_raw_over_expected_gemv_t": gemv_fetch * KIB / gemv_expected,
         "fetch_correction_factor": fetch_factor,
@@ -82,10 +84,10 @@ out = {
     "kernel_stats": [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage")} for r in stats[:14]],
 }
 os.makedirs("profiles", exist_ok=True)
-with open(os.path.join("profiles", f"{tag}_n{n}_summary.json"), "w") as f:
+with open(os.path.join("profiles", f"{tag}_n{n}{suffix}_summary.json"), "w") as f:
     json.dump(out, f, indent=1)
-shutil.copy(os.path.join(src, "stats", "st_kernel_stats.csv"), os.path.join("profiles", f"{tag}_n{n}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "stats", "st_kernel_stats.csv"), os.path.join("profiles", f"{tag}_n{n}{suffix}_kernel_stats.csv"))
 for p in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_mops"):
-    shutil.copy(os.path.join(src, p, "per_kernel.json"), os.path.join("profiles", f"{tag}_n{n}_{p}_per_kernel.json"))
+    shutil.copy(os.path.join(src, p, "per_kernel.json"), os.path.join("profiles", f"{tag}_n{n}{suffix}_{p}_per_kernel.json"))
 print(json.dumps(out["calibration"]))
 print(json.dumps({k: (v["mfma_util"], v["hbm_bytes_per_dispatch"], v["effective_clock_ghz"]) for k, v in classes.items()}))
