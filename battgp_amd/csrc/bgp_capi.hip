@@ -125,11 +125,14 @@ struct PhaseTimer {
 //      st:          [wait panel(0)] rest(0) [wait panel(1)] rest(1) ...
 //  Every element still receives exactly the same single rank-NB update, so the factor is
 //  bit-identical with and without look-ahead.
+// `A` is the origin of the panel's slab (or of a stand-alone panel), K0 the panel's first column
+// relative to it and `gofs` the global index of that origin (tile inverses and the failing-minor
+// report are indexed globally).
 int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t nrows, int64_t lda, double* inv, int* dinfo,
-                 int64_t K0, int64_t nbk) {
+                 int64_t K0, int64_t nbk, int64_t gofs = 0) {
   for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
-    double* inv_j = inv + (j / BGP_IB) * (BGP_IB * BGP_IB);
-    int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)j, 64);
+    double* inv_j = inv + ((j + gofs) / BGP_IB) * (BGP_IB * BGP_IB);
+    int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)(j + gofs), 64);
     if (rc) return rc;
     const int64_t rows_below = nrows - (j + BGP_IB);
     if (rows_below > 0) {
@@ -162,9 +165,9 @@ struct TrailTimer {
     BGP_HIP(h, hipEventRecord(h->ev_pool[used], st));
     return 0;
   }
-  int end(hipStream_t st, double m, double ncols_full, double k, bool square) {
-    // algorithmic flop of a lower (trapezoid) rank-k update: 2 k * #entries(i >= j)
-    flop += square ? m * (m + 1.0) * k : 2.0 * k * (ncols_full * (m - ncols_full) + ncols_full * (ncols_full + 1.0) / 2.0);
+  int end(hipStream_t st, double m, double ncols, double k) {
+    // algorithmic flop of a lower (trapezoid, m rows x ncols columns) rank-k update: 2 k * #entries(i >= j)
+    flop += 2.0 * k * (ncols * (m - ncols) + ncols * (ncols + 1.0) / 2.0);
     if (!on) return 0;
     BGP_HIP(h, hipEventRecord(h->ev_pool[used + 1], st));
     used += 2;
@@ -206,10 +209,14 @@ int check_info(bgp_handle* h, hipStream_t st, hipStream_t sp, int* dinfo, int* o
 // `nrows >= n`: rows n..nrows-1 are extra rows BELOW the square matrix (the augmented block whose
 // row n carries y^T): they ride through every TRSM / update like any other row below the
 // diagonal and come out as (L^-1 y)^T - the forward solve costs no launch of its own.
-int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t nrows, int64_t lda, double* inv,
+// The matrix lives in column slabs (SlabView): a trailing update is one launch per slab it touches
+// (one launch in the full-square layout); panels never straddle a slab.
+int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, int64_t nrows, double* inv,
                  int* dinfo, int* info_out, bool time_trailing) {
   const int64_t NB = h->nb_outer;
   const int64_t extra = nrows - n;
+  if (V.W < n && (V.W % NB) != 0)
+    return bgp_fail(h, -1, "slab width %lld is not a multiple of nb_outer=%lld", (long long)V.W, (long long)NB);
   const bool la = h->lookahead != 0 && n > 2 * NB;
   hipStream_t sp = la ? h->s_aux : st;
   BGP_HIP(h, hipMemsetAsync(dinfo, 0, sizeof(int), st));
@@ -222,22 +229,36 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t nr
     BGP_HIP(h, hipEventRecord(ev, st));
     BGP_HIP(h, hipStreamWaitEvent(sp, ev, 0));
   }
+  // rank-nbk update of columns [c_begin, c_end) (all rows from the diagonal down + the extra rows) by
+  // panel K0: one launch per slab
+  auto update = [&](hipStream_t s, int tmode, int64_t K0, int64_t nbk, int64_t c_begin, int64_t c_end) -> int {
+    const int64_t ldp = V.ld(K0);
+    for (int64_t c_lo = c_begin; c_lo < c_end;) {
+      const int64_t c_hi = V.slab_end(c_lo, c_end);
+      const double* P = V.at(c_lo, K0);
+      int r;
+      if ((r = tt.begin(s))) return r;
+      r = launch_gemm_nt(h, s, tmode, 128, V.at(c_lo, c_lo), V.ld(c_lo), P, ldp, P, ldp, (n - c_lo) + extra,
+                         c_hi - c_lo, nbk, 1, dinfo);
+      if (r) return r;
+      if ((r = tt.end(s, (double)(n - c_lo), (double)(c_hi - c_lo), (double)nbk))) return r;
+      c_lo = c_hi;
+    }
+    return 0;
+  };
   int step = 0;
   for (int64_t K0 = 0; K0 < n; K0 += NB, ++step) {
     const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
     const int64_t K1 = K0 + nbk;
     const int64_t rows_trail = n - K1;
-    if ((rc = factor_panel(h, sp, A, nrows, lda, inv, dinfo, K0, nbk))) return rc;
+    const int64_t s0 = V.slab(K0) * V.W;  // origin of the panel's slab
+    if ((rc = factor_panel(h, sp, V.at(s0, s0), nrows - s0, V.ld(K0), inv, dinfo, K0 - s0, nbk, s0))) return rc;
     // deep rank-NB updates accumulate through L2 atomics (no C read in the tile prologue: +4 % at k = 512);
     // shallow ones keep the read-modify-write form (atomics lose below k ~ 256)
     const int tmode = (nbk >= 256 && h->lookahead != 3) ? 2 : 0;
     if (rows_trail > 0) {
-      double* P = A + K1 + K0 * lda;
       if (!la) {
-        if ((rc = tt.begin(st))) return rc;
-        rc = launch_gemm_nt(h, st, tmode, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail + extra, rows_trail, nbk, 1, dinfo);
-        if (rc) return rc;
-        if ((rc = tt.end(st, (double)rows_trail, (double)rows_trail, (double)nbk, true))) return rc;
+        if ((rc = update(st, tmode, K0, nbk, K1, n))) return rc;
       } else {
         const int64_t nbn = (rows_trail < NB) ? rows_trail : NB;  // width of the next panel
         const int64_t K2 = K1 + nbn;
@@ -247,20 +268,9 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t nr
         BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
         // la(k) on sp rewrites columns that rest(k-1) also updated: order it after rest(k-1)
         if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + 2 * (size_t)(step - 1)], 0));
-        if ((rc = tt.begin(sp))) return rc;
-        rc = launch_gemm_nt(h, sp, tmode, 128, A + K1 + K1 * lda, lda, P, lda, P, lda, rows_trail + extra, nbn, nbk, 1, dinfo);
-        if (rc) return rc;
-        if ((rc = tt.end(sp, (double)rows_trail, (double)nbn, (double)nbk, false))) return rc;
+        if ((rc = update(sp, tmode, K0, nbk, K1, K2))) return rc;
         // rest(k) on st: everything right of the next panel
-        const int64_t rows_rest = n - K2;
-        if (rows_rest > 0) {
-          const double* P2 = A + K2 + K0 * lda;
-          if ((rc = tt.begin(st))) return rc;
-          rc = launch_gemm_nt(h, st, tmode, 128, A + K2 + K2 * lda, lda, P2, lda, P2, lda, rows_rest + extra, rows_rest,
-                              nbk, 1, dinfo);
-          if (rc) return rc;
-          if ((rc = tt.end(st, (double)rows_rest, (double)rows_rest, (double)nbk, true))) return rc;
-        }
+        if (n - K2 > 0 && (rc = update(st, tmode, K0, nbk, K2, n))) return rc;
         if ((rc = sync_event(h, 2 + 2 * (size_t)step, &ev))) return rc;
         BGP_HIP(h, hipEventRecord(ev, st));
       }
@@ -275,11 +285,12 @@ int potrf_driver(bgp_handle* h, hipStream_t st, double* A, int64_t n, int64_t nr
 // ---- E <- E L^-T for a row block E[me, n] (column-major, rows contiguous) --------------------
 // Same two-level blocking as the factorisation: the rows of E are "extra rows below the
 // matrix".  Used for z^T = (L^-1 y)^T (me = 16, row 0) and V^T = (L^-1 K_X*)^T.
-int epass_driver(bgp_handle* h, hipStream_t st, double* E, int64_t lde, int64_t me, const double* A,
-                 int64_t n, int64_t lda, const double* inv) {
+int epass_driver(bgp_handle* h, hipStream_t st, double* E, int64_t lde, int64_t me, const SlabView& A, int64_t n,
+                 const double* inv) {
   const int64_t NB = h->nb_outer;
   for (int64_t K0 = 0; K0 < n; K0 += NB) {
     const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    const int64_t lda = A.ld(K0);
     for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
       const double* inv_j = inv + (j / BGP_IB) * (BGP_IB * BGP_IB);
       double* Ej = E + j * lde;
@@ -288,14 +299,14 @@ int epass_driver(bgp_handle* h, hipStream_t st, double* E, int64_t lde, int64_t 
       const int64_t ncols = K0 + nbk - (j + BGP_IB);
       if (ncols > 0) {
         rc = launch_gemm_nt(h, st, 0, ncols >= 128 ? 128 : 64, E + (j + BGP_IB) * lde, lde, Ej, lde,
-                            A + (j + BGP_IB) + j * lda, lda, me, ncols, BGP_IB, 0);
+                            A.at(j + BGP_IB, j), lda, me, ncols, BGP_IB, 0);
         if (rc) return rc;
       }
     }
     const int64_t rows_trail = n - (K0 + nbk);
     if (rows_trail > 0) {
-      int rc = launch_gemm_nt(h, st, 0, 128, E + (K0 + nbk) * lde, lde, E + K0 * lde, lde,
-                              A + (K0 + nbk) + K0 * lda, lda, me, rows_trail, nbk, 0);
+      int rc = launch_gemm_nt(h, st, 0, 128, E + (K0 + nbk) * lde, lde, E + K0 * lde, lde, A.at(K0 + nbk, K0), lda, me,
+                              rows_trail, nbk, 0);
       if (rc) return rc;
     }
   }
@@ -314,7 +325,8 @@ int ensure_part(bgp_handle* h, int64_t need) {
 
 // alpha = L^-T z
 int backward_driver(bgp_handle* h, hipStream_t st) {
-  const int64_t n = h->Npad, lda = h->lda, NB = h->nb_outer;
+  const int64_t n = h->Npad, NB = h->nb_outer;
+  const SlabView V = h->view();
   int rc = ensure_part(h, ((n + 1023) / 1024 + 1) * NB);
   if (rc) return rc;
   const int64_t nblk = (n + NB - 1) / NB;
@@ -324,10 +336,10 @@ int backward_driver(bgp_handle* h, hipStream_t st) {
     const int64_t K1 = K0 + nbk;
     int nch = 0;
     if (n - K1 > 0) {
-      rc = launch_gemv_t_partial(h, st, h->dA + K1 + K0 * lda, lda, h->dalpha + K1, n - K1, (int)nbk, h->dpart, &nch);
+      rc = launch_gemv_t_partial(h, st, V.at(K1, K0), V.ld(K0), h->dalpha + K1, n - K1, (int)nbk, h->dpart, &nch);
       if (rc) return rc;
     }
-    rc = launch_trsv_block_bwd(h, st, h->dA + K0 + K0 * lda, lda, h->dInv + (K0 / BGP_IB) * (BGP_IB * BGP_IB),
+    rc = launch_trsv_block_bwd(h, st, V.at(K0, K0), V.ld(K0), h->dInv + (K0 / BGP_IB) * (BGP_IB * BGP_IB),
                                h->dz + K0, h->dpart, nch, (int)nbk, h->dalpha + K0);
     if (rc) return rc;
   }
@@ -335,7 +347,9 @@ int backward_driver(bgp_handle* h, hipStream_t st) {
 }
 
 void free_problem(bgp_handle* h) {
-  dev_free(h, &h->dA, h->lda * h->Npad);
+  dev_free(h, &h->dA, h->A_doubles);
+  h->A_doubles = 0;
+  h->slabW = BGP_W_FULL;
   dev_free(h, &h->dInv, h->Npad * BGP_IB);
   dev_free(h, &h->dz, h->Npad);
   dev_free(h, &h->dalpha, h->Npad);
@@ -350,6 +364,37 @@ void free_problem(bgp_handle* h) {
   h->fitted = false;
 }
 
+// Layout of the factor: full square when it fits (one launch per trailing update), column slabs
+// otherwise (SlabView in bgp_internal.h; ~4 N (N + W) bytes instead of 8 N^2).
+int choose_slab_width(bgp_handle* h, int64_t Npad, int64_t lda, int64_t* W_out) {
+  const int64_t NB = h->nb_outer;
+  if (h->slab_req < 0) {
+    *W_out = BGP_W_FULL;
+    return 0;
+  }
+  if (h->slab_req > 0) {
+    if ((h->slab_req % NB) != 0 || (h->slab_req & 1))
+      return bgp_fail(h, -1, "slab width %lld must be a multiple of nb_outer=%lld", (long long)h->slab_req, (long long)NB);
+    *W_out = h->slab_req >= Npad ? BGP_W_FULL : h->slab_req;
+    return 0;
+  }
+  size_t free_b = 0, total_b = 0;
+  BGP_HIP(h, hipMemGetInfo(&free_b, &total_b));
+  const double margin = 1.5e9;  // workspaces, query buffers, runtime
+  if ((double)lda * (double)Npad * 8.0 + margin <= (double)free_b) {
+    *W_out = BGP_W_FULL;
+    return 0;
+  }
+  int64_t W = 65536;
+  for (; W > NB; W /= 2) {
+    if ((W % NB) != 0 || W >= Npad) continue;
+    if ((double)SlabView::total(lda, W, Npad) * 8.0 + margin <= (double)free_b) break;
+  }
+  if (W < NB || (W % NB) != 0) W = NB;  // the narrowest layout; hipMalloc reports if even that does not fit
+  *W_out = W >= Npad ? BGP_W_FULL : W;
+  return 0;
+}
+
 int alloc_problem(bgp_handle* h, int64_t N, int D, int64_t Mride) {
   const int64_t aug_need = BGP_AUG + round_up(Mride, 64);
   if (h->N == N && h->D == D && h->dA && h->aug_cap >= aug_need) return 0;
@@ -360,22 +405,27 @@ int alloc_problem(bgp_handle* h, int64_t N, int D, int64_t Mride) {
   // columns of a tile in one HBM channel)
   int64_t lda = Npad + aug_need;
   if (lda >= 2048 && (lda % 512) == 0) lda += 64;
+  int64_t W = BGP_W_FULL;
+  int rc;
+  if ((rc = choose_slab_width(h, Npad, lda, &W))) return rc;
   h->N = N;
   h->D = D;
   h->Npad = Npad;
   h->lda = lda;
+  h->slabW = W;
   h->aug_cap = aug_need;
   h->aug_used = BGP_AUG;
-  int rc;
   if ((rc = dev_alloc(h, &h->dX, N * D))) return rc;
   if ((rc = dev_alloc(h, &h->dy, N))) return rc;
   if ((rc = dev_alloc(h, &h->dInv, Npad * BGP_IB))) return rc;
   if ((rc = dev_alloc(h, &h->dz, Npad))) return rc;
   if ((rc = dev_alloc(h, &h->dalpha, Npad))) return rc;
-  if ((rc = dev_alloc(h, &h->dA, lda * Npad))) {
+  const int64_t need = SlabView::total(lda, W, Npad);
+  if ((rc = dev_alloc(h, &h->dA, need))) {
     free_problem(h);
     return rc;
   }
+  h->A_doubles = need;
   return 0;
 }
 
@@ -384,7 +434,8 @@ int alloc_problem(bgp_handle* h, int64_t N, int D, int64_t Mride) {
 // factorisation below the augmented y block and come out as V^T = K_*X L^-T (no separate solve pass)
 int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mride = 0) {
   hipStream_t st = h->s_main;
-  const int64_t N = h->N, Npad = h->Npad, lda = h->lda;
+  const int64_t N = h->N, Npad = h->Npad;
+  const SlabView V = h->view();
   h->fitted = false;
   h->times[BGP_T_FILL] = h->times[BGP_T_POTRF] = h->times[BGP_T_CROSS] = 0.0;
   const int64_t ride_rows = round_up(Mride, 64);
@@ -398,20 +449,33 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mri
     if (rc) return rc;
     {
       PhaseTimer t(h, st, BGP_T_FILL, true);
-      rc = launch_fill(h, st, p, h->dX, Npad, h->dX, Npad, h->dA, lda, 1, 1, N, N);
-      if (rc) return rc;
-      if ((rc = launch_aug_rows(h, st, h->dy, N, h->dA + Npad, lda, Npad, BGP_AUG))) return rc;
+      // per column slab: the lower trapezoid from the slab's diagonal down + its part of the y^T block
+      // (x pointers are only dereferenced for indices < nvalid, so offsets past N are never read)
+      for (int64_t c0 = 0; c0 < Npad;) {
+        const int64_t c1 = V.slab_end(c0, Npad);
+        const int64_t nv = N > c0 ? N - c0 : 0;
+        const double* xs = h->dX + c0 * h->D;
+        rc = launch_fill(h, st, p, xs, Npad - c0, xs, c1 - c0, V.at(c0, c0), V.ld(c0), 1, 1, nv, nv);
+        if (rc) return rc;
+        if ((rc = launch_aug_rows(h, st, h->dy + c0, nv, V.at(Npad, c0), V.ld(c0), c1 - c0, BGP_AUG))) return rc;
+        c0 = c1;
+      }
       if ((rc = t.stop())) return rc;
     }
     if (Mride > 0) {
       PhaseTimer t(h, st, BGP_T_CROSS, true);
-      rc = launch_fill(h, st, p, h->dXq, ride_rows, h->dX, Npad, h->dA + Npad + BGP_AUG, lda, 0, 0, Mride, N);
-      if (rc) return rc;
+      for (int64_t c0 = 0; c0 < Npad;) {
+        const int64_t c1 = V.slab_end(c0, Npad);
+        rc = launch_fill(h, st, p, h->dXq, ride_rows, h->dX + c0 * h->D, c1 - c0, V.at(Npad + BGP_AUG, c0), V.ld(c0), 0,
+                         0, Mride, N > c0 ? N - c0 : 0);
+        if (rc) return rc;
+        c0 = c1;
+      }
       if ((rc = t.stop())) return rc;
     }
     {
       PhaseTimer t(h, st, BGP_T_POTRF, true);
-      rc = potrf_driver(h, st, h->dA, Npad, Npad + h->aug_used, lda, h->dInv, h->dinfo, &info, true);
+      rc = potrf_driver(h, st, V, Npad, Npad + h->aug_used, h->dInv, h->dinfo, &info, true);
       if (rc) return rc;
       if ((rc = t.stop())) return rc;
     }
@@ -430,8 +494,12 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mri
     int rc;
     // z^T = row Npad of the factor (came out of the factorisation); alpha = L^-T z is computed
     // lazily (ensure_alpha) - the predictive path with variance never needs it
-    if ((rc = launch_gather_row(h, st, h->dA + Npad, lda, Npad, h->dz))) return rc;
-    if ((rc = launch_fit_scalars(h, st, h->dA, lda, h->dz, 1, Npad, h->dscal))) return rc;
+    for (int64_t c0 = 0; c0 < Npad;) {
+      const int64_t c1 = V.slab_end(c0, Npad);
+      if ((rc = launch_gather_row(h, st, V.at(Npad, c0), V.ld(c0), c1 - c0, h->dz + c0))) return rc;
+      c0 = c1;
+    }
+    if ((rc = launch_fit_scalars(h, st, V, h->dz, 1, Npad, h->dscal))) return rc;
     BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     if ((rc = t.stop())) return rc;
   }
@@ -492,13 +560,29 @@ int ride_posterior(bgp_handle* h, int64_t M, bool want_var, double min_var) {
   FillParams p;
   int rc = make_fill_params(h, h->D, 0.0, &p);
   if (rc) return rc;
-  const double* E = h->dA + h->Npad + BGP_AUG;
+  const SlabView V = h->view();
+  const int64_t Npad = h->Npad;
+  // partial row sums per 512-column chunk, slab by slab (slab widths are multiples of the chunk)
+  auto rowdot_all = [&](const double* vec, int* nch_out) -> int {
+    int nch = 0;
+    for (int64_t c0 = 0; c0 < Npad;) {
+      const int64_t c1 = V.slab_end(c0, Npad);
+      int q = 0;
+      int r = launch_rowdot(h, st, V.at(Npad + BGP_AUG, c0), V.ld(c0), M, c1 - c0, vec ? vec + c0 : nullptr,
+                            h->dpart + (int64_t)nch * M, &q);
+      if (r) return r;
+      nch += q;
+      c0 = c1;
+    }
+    *nch_out = nch;
+    return 0;
+  };
   PhaseTimer t(h, st, BGP_T_VAR);
   int nch = 0;
-  if ((rc = launch_rowdot(h, st, E, h->lda, M, h->Npad, h->dz, h->dpart, &nch))) return rc;
+  if ((rc = rowdot_all(h->dz, &nch))) return rc;
   if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, nullptr, &p, -1.0, h->dout))) return rc;
   if (want_var) {
-    if ((rc = launch_rowdot(h, st, E, h->lda, M, h->Npad, nullptr, h->dpart, &nch))) return rc;
+    if ((rc = rowdot_all(nullptr, &nch))) return rc;
     if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, h->dXq, &p, min_var, h->dout + M))) return rc;
   }
   return t.stop();
@@ -532,7 +616,7 @@ int predict_resident(bgp_handle* h, int64_t M, bool want_var, double min_var) {
     // V^T = K_*X L^-T, then  mean = V^T z  (= K_*X alpha without the backward solve) and
     // var = k_** - rowsumsq(V^T)
     PhaseTimer t(h, st, BGP_T_VAR);
-    if ((rc = epass_driver(h, st, h->dE, lde, Mpad, h->dA, Npad, h->lda, h->dInv))) return rc;
+    if ((rc = epass_driver(h, st, h->dE, lde, Mpad, h->view(), Npad, h->dInv))) return rc;
     int nch = 0;
     if ((rc = launch_rowdot(h, st, h->dE, lde, M, Npad, h->dz, h->dpart, &nch))) return rc;
     if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, M, nullptr, &p, -1.0, h->dout))) return rc;
@@ -646,6 +730,28 @@ int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, 
   if (max_tries >= 0) h->max_tries = max_tries;
   if (jitter0 >= 0.0) h->jitter0 = jitter0;
   if (lookahead >= 0) h->lookahead = lookahead;
+  return 0;
+}
+
+int bgp_set_layout(bgp_handle* h, int64_t slab_width) {
+  if (!h) return -1;
+  if (slab_width < -1) return bgp_fail(h, -1, "bgp_set_layout: slab_width must be -1, 0 or a positive width");
+  if (slab_width > 0 && ((slab_width % BGP_IB) != 0))
+    return bgp_fail(h, -1, "bgp_set_layout: slab_width must be a multiple of %d (and of nb_outer)", BGP_IB);
+  if (slab_width != h->slab_req) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->s_main) (void)hipStreamSynchronize(h->s_main);
+    free_problem(h);
+    h->slab_req = slab_width;
+  }
+  return 0;
+}
+
+int bgp_get_layout(const bgp_handle* h, int64_t* slab_width_out, int64_t* factor_bytes_out) {
+  if (!h) return -1;
+  if (slab_width_out) *slab_width_out = (h->dA && h->slabW < h->Npad) ? h->slabW : 0;
+  if (factor_bytes_out) *factor_bytes_out = h->A_doubles * 8;
   return 0;
 }
 
@@ -848,7 +954,7 @@ int bgp_residuals(bgp_handle* h, int nsample, double* out2) {
   if ((rc = launch_kmatvec(h, st, p, h->dX, h->N, h->dalpha, diag_add, dr))) return rc;
   if ((rc = launch_norm2(h, st, dr, h->dy, h->N, h->dscal + 2))) return rc;
   if ((rc = launch_norm2(h, st, h->dy, nullptr, h->N, h->dscal + 3))) return rc;
-  if ((rc = launch_llt_sample(h, st, p, h->dX, h->dA, h->lda, h->N, diag_add, nsample, derr))) return rc;
+  if ((rc = launch_llt_sample(h, st, p, h->dX, h->view(), h->N, diag_add, nsample, derr))) return rc;
   std::vector<double> herr((size_t)nsample);
   BGP_HIP(h, hipMemcpyAsync(h->hscal + 2, h->dscal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
   BGP_HIP(h, hipMemcpyAsync(herr.data(), derr, (size_t)nsample * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -878,7 +984,7 @@ int bgp_potrf_dev(bgp_handle* h, double* A_dev, int64_t n, int64_t lda, int* inf
   int info = 0;
   {
     PhaseTimer t(h, h->s_main, BGP_T_POTRF);
-    rc = potrf_driver(h, h->s_main, A_dev, n, n, lda, inv, h->dinfo, &info, true);
+    rc = potrf_driver(h, h->s_main, SlabView{A_dev, lda, BGP_W_FULL}, n, n, inv, h->dinfo, &info, true);
     if (!rc) rc = t.stop();
   }
   dev_free(h, &inv, n * BGP_IB);
@@ -954,7 +1060,7 @@ int bgp_solve_panel_dev(bgp_handle* h, double* E_dev, int64_t lde, int64_t me, c
   int rc = check_handle(h);
   if (rc) return rc;
   if (nbk > h->nb_outer) return bgp_fail(h, -1, "bgp_solve_panel_dev: nbk=%d exceeds nb_outer=%d", nbk, h->nb_outer);
-  return epass_driver(h, h->s_main, E_dev, lde, me, Lkk_dev, nbk, ld, inv_dev);
+  return epass_driver(h, h->s_main, E_dev, lde, me, SlabView{const_cast<double*>(Lkk_dev), ld, BGP_W_FULL}, nbk, inv_dev);
 }
 
 int bgp_gemm_nt_sub_async_dev(bgp_handle* h, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
@@ -968,7 +1074,8 @@ int bgp_diag_logsum_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t 
   int rc = check_handle(h);
   if (rc) return rc;
   // fit_scalars sums log of the diagonal and the squares of a vector: reuse with z = the diagonal itself
-  if ((rc = launch_fit_scalars(h, h->s_main, A_dev, ld, A_dev, ld + 1, n, h->dscal + 4))) return rc;
+  if ((rc = launch_fit_scalars(h, h->s_main, SlabView{const_cast<double*>(A_dev), ld, BGP_W_FULL}, A_dev, ld + 1, n, h->dscal + 4)))
+    return rc;
   BGP_HIP(h, hipMemcpyAsync(h->hscal + 4, h->dscal + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, h->s_main));
   BGP_HIP(h, hipStreamSynchronize(h->s_main));
   if (out_host) *out_host = h->hscal[4];
@@ -1015,7 +1122,7 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   if (!h->dB && (rc = dev_alloc(h, &h->dB, lda * n))) return rc;
   if (!h->dS && (rc = dev_alloc(h, &h->dS, lda * n))) return rc;
   double *U = h->dB, *S = h->dS;
-  const double* L = h->dA;
+  const SlabView L = h->view();  // U and S are plain [lda, n] squares of their own
   const double* inv = h->dInv;
   PhaseTimer t(h, st, BGP_T_SOLVE);
   // (1) U = I L^-T (upper triangular): the identity pushed through the panel operations row-block-wise;
@@ -1033,10 +1140,10 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
       const int64_t ncols = K1 - (j + BGP_IB);
       if (ncols > 0 &&
           (rc = launch_gemm_nt(h, st, 0, ncols >= 128 ? 128 : 64, U + (j + BGP_IB) * lda, lda, Uj, lda,
-                               L + (j + BGP_IB) + j * lda, lda, act, ncols, BGP_IB, 0)))
+                               L.at(j + BGP_IB, j), L.ld(j), act, ncols, BGP_IB, 0)))
         return rc;
     }
-    if (n - K1 > 0 && (rc = launch_gemm_nt(h, st, 0, 128, U + K1 * lda, lda, U + K0 * lda, lda, L + K1 + K0 * lda, lda,
+    if (n - K1 > 0 && (rc = launch_gemm_nt(h, st, 0, 128, U + K1 * lda, lda, U + K0 * lda, lda, L.at(K1, K0), L.ld(K0),
                                            K1, n - K1, nbk, 0)))
       return rc;
   }

@@ -151,6 +151,14 @@ __host__ int64_t lower_blocks(int nti) {
   return (int64_t)FT_RATIO * ((int64_t)nti * nti - (int64_t)nti * (nti - 1) / 2);
 }
 
+// blocks of a lower trapezoid that is only ntj column tiles wide (a column slab): the enumeration is
+// column-group-major, so the needed tiles are a prefix - do not launch the empty remainder
+__host__ int64_t lower_blocks(int nti, int ntj) {
+  int64_t G = (ntj + FT_RATIO - 1) / FT_RATIO;
+  if (G > nti) G = nti;
+  return (int64_t)FT_RATIO * (G * nti - G * (G - 1) / 2);
+}
+
 // ABL != 0: ablation variants for tools/fill_ablate.hip only (1 = no kernel math, 2 = no stores)
 template <int KID, int DT, int ABL = 0>
 __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* __restrict__ x1,
@@ -256,7 +264,7 @@ int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t
                   int64_t n2, double* out, int64_t ld, int lower, int add_diag, int64_t nv1,
                   int64_t nv2) {
   const int nti = (int)((n1 + FT_ROWS - 1) / FT_ROWS), ntj = (int)((n2 + FT_COLS - 1) / FT_COLS);
-  int64_t nblocks = lower ? lower_blocks(nti) : (int64_t)nti * ntj;
+  int64_t nblocks = lower ? lower_blocks(nti, ntj) : (int64_t)nti * ntj;
   if (nblocks <= 0) return 0;
   if (nblocks > 0x7fffffffLL) return -1;
   const int vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -314,8 +322,7 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(FillParams p, const double
 // sampled check of (L L^T)_ij against Sigma_ij: one wave per sample
 template <int KID>
 __global__ __launch_bounds__(64) void llt_sample_kernel(FillParams p, const double* __restrict__ x,
-                                                        const double* __restrict__ L, int64_t lda,
-                                                        int64_t n, double diag_add, int nsample,
+                                                        SlabView L, int64_t n, double diag_add, int nsample,
                                                         double* __restrict__ out_err) {
   constexpr int DD = BGP_MAX_DIM;
   const int s = blockIdx.x;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(64) void llt_sample_kernel(FillParams p, const doub
   if (s == 0) { i = n - 1; j = n - 1; }
   if (s == 1) { i = n - 1; j = 0; }
   double acc = 0.0;
-  for (int64_t q = threadIdx.x; q <= j; q += 64) acc = __builtin_fma(L[i + q * lda], L[j + q * lda], acc);
+  for (int64_t q = threadIdx.x; q <= j; q += 64) acc = __builtin_fma(*L.at(i, q), *L.at(j, q), acc);
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
   if (threadIdx.x == 0) {
     double a[DD], b[DD];
@@ -499,10 +506,10 @@ int launch_kmatvec(bgp_handle* h, hipStream_t st, const FillParams& p, const dou
 }
 
 int launch_llt_sample(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x,
-                      const double* L, int64_t lda, int64_t n, double diag_add, int nsample,
+                      const SlabView& L, int64_t n, double diag_add, int nsample,
                       double* out_err) {
   dim3 grid((unsigned)nsample), block(64);
-  BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((llt_sample_kernel<KID_>), grid, block, 0, st, p, x, L, lda,
+  BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((llt_sample_kernel<KID_>), grid, block, 0, st, p, x, L,
                                            n, diag_add, nsample, out_err));
   BGP_HIP(h, hipGetLastError());
   return 0;

@@ -21,6 +21,38 @@ struct FillParams {
   double scale[BGP_MAX_DIM];  // per-column input scale: 1/(l*sqrt 2) (RBF) or sqrt(3)/l (Matern); K0 col 0 unused
 };
 
+// Storage of the in-place covariance / factor.  The columns are cut into slabs of width W; slab g
+// keeps only rows [g W, L) - nothing above its own diagonal block - as one column-major block
+// with leading dimension L - g W, slabs back to back.  W >= Npad is the plain full-square layout
+// (one slab, ld = L).  With W << N the footprint drops from 8 N^2 to ~4 N (N + W) bytes, which is
+// what lets N = 262 144 live on ONE 288 GB MI355X.  Every launch of the path works on columns of
+// one slab (panels never straddle: W is a multiple of the outer panel width), so the kernels keep
+// their plain (pointer, ld) interface.
+struct SlabView {
+  double* base;
+  int64_t L;  // rows of slab 0 (= Npad + rows riding below the matrix)
+  int64_t W;  // slab width in columns
+  __host__ __device__ int64_t slab(int64_t c) const { return c / W; }
+  __host__ __device__ int64_t ld(int64_t c) const { return L - slab(c) * W; }
+  __host__ __device__ int64_t offset(int64_t r, int64_t c) const {
+    const int64_t g = c / W, c0 = g * W;
+    return W * (g * L - W * (g * (g - 1) / 2)) + (r - c0) + (c - c0) * (L - c0);
+  }
+  __host__ __device__ double* at(int64_t r, int64_t c) const { return base + offset(r, c); }
+  // first column after c's slab, clipped to n
+  __host__ __device__ int64_t slab_end(int64_t c, int64_t n) const {
+    const int64_t e = (slab(c) + 1) * W;
+    return (e < n && e > 0) ? e : n;
+  }
+  // doubles needed for ncols columns
+  static int64_t total(int64_t L, int64_t W, int64_t ncols) {
+    int64_t t = 0;
+    for (int64_t c0 = 0; c0 < ncols; c0 += W) t += (L - c0) * ((ncols - c0 < W) ? (ncols - c0) : W);
+    return t;
+  }
+};
+#define BGP_W_FULL ((int64_t)1 << 40)  // "one slab": any W >= Npad
+
 struct bgp_handle {
   int device = 0;
   hipStream_t s_main = nullptr, s_aux = nullptr;
@@ -36,8 +68,12 @@ struct bgp_handle {
   int max_tries = 3;
   double jitter0 = 1e-8;
   int lookahead = 1;
+  int64_t slab_req = 0;  // bgp_set_layout: 0 auto (full square if it fits, else slabs), -1 full square, > 0 width
   // problem
   int64_t N = 0, Npad = 0, lda = 0;
+  int64_t slabW = BGP_W_FULL;  // slab width of dA (BGP_W_FULL: full-square layout, ld = lda)
+  int64_t A_doubles = 0;       // allocated size of dA
+  SlabView view() const { return SlabView{dA, lda, slabW}; }
   int64_t aug_cap = BGP_AUG;   // rows allocated below the matrix: 64 (y block) + room for riding query rows
   int64_t aug_used = BGP_AUG;  // rows of it that took part in the last factorisation
   int D = 0;
@@ -47,7 +83,7 @@ struct bgp_handle {
   // device buffers
   double* dX = nullptr;      // [N, D] row-major
   double* dy = nullptr;      // [N]
-  double* dA = nullptr;      // [lda, Npad] column-major, lower triangle = Sigma then L
+  double* dA = nullptr;      // column slabs (SlabView) of [lda, Npad] column-major, lower triangle = Sigma then L
   double* dInv = nullptr;    // [Npad/64][64*64] inverses of the diagonal tiles of L
   double* dz = nullptr;      // [Npad] z = L^-1 y (zero in the padding)
   double* dalpha = nullptr;  // [Npad]
@@ -90,7 +126,7 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
                    int64_t k, int lower, const int* abort_flag = nullptr);
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv,
                       int* info, int col0, int nvalid);
-int launch_fit_scalars(bgp_handle* h, hipStream_t st, const double* A, int64_t lda, const double* z,
+int launch_fit_scalars(bgp_handle* h, hipStream_t st, const SlabView& A, const double* z,
                        int64_t ldz, int64_t n, double* out2);
 int launch_aug_rows(bgp_handle* h, hipStream_t st, const double* y, int64_t n, double* Aaug, int64_t lda,
                     int64_t ncols, int naug);  // Aaug[r + j*lda] = (r == 0 && j < n) ? y[j] : 0
@@ -107,7 +143,7 @@ int launch_rowdot_finish(bgp_handle* h, hipStream_t st, const double* part, int 
 int launch_kmatvec(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n,
                    const double* v, double diag_add, double* out);
 int launch_llt_sample(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x,
-                      const double* L, int64_t lda, int64_t n, double diag_add, int nsample,
+                      const SlabView& L, int64_t n, double diag_add, int nsample,
                       double* out_max);
 int launch_norm2(bgp_handle* h, hipStream_t st, const double* a, const double* b /*null*/, int64_t n,
                  double* out);  // out[0] = sum (a-b)^2 or sum a^2

@@ -364,13 +364,12 @@ __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(double* __restrict__
 }
 
 // out[0] = sum_i log A_ii, out[1] = sum_i z_i^2   (z strided by ldz).  One workgroup.
-__global__ __launch_bounds__(1024) void fit_scalars_kernel(const double* __restrict__ A, int64_t lda,
-                                                           const double* __restrict__ z, int64_t ldz,
+__global__ __launch_bounds__(1024) void fit_scalars_kernel(SlabView A, const double* __restrict__ z, int64_t ldz,
                                                            int64_t n, double* __restrict__ out) {
   __shared__ double r0[1024], r1[1024];
   double a = 0.0, b = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) {
-    a += log(A[i + i * lda]);
+    a += log(*A.at(i, i));
     const double zi = z[i * ldz];
     b = __builtin_fma(zi, zi, b);
   }
@@ -612,9 +611,9 @@ int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, d
   return 0;
 }
 
-int launch_fit_scalars(bgp_handle* h, hipStream_t st, const double* A, int64_t lda, const double* z,
+int launch_fit_scalars(bgp_handle* h, hipStream_t st, const SlabView& A, const double* z,
                        int64_t ldz, int64_t n, double* out2) {
-  hipLaunchKernelGGL(fit_scalars_kernel, dim3(1), dim3(1024), 0, st, A, lda, z, ldz, n, out2);
+  hipLaunchKernelGGL(fit_scalars_kernel, dim3(1), dim3(1024), 0, st, A, z, ldz, n, out2);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

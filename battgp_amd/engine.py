@@ -94,6 +94,17 @@ class ExactGPEngine:
     def set_options(self, nb_outer=-1, max_tries=-1, jitter0=-1.0, lookahead=-1) -> None:
         self._check(self._lib.bgp_set_options(self._h, nb_outer, max_tries, jitter0, lookahead), "bgp_set_options")
 
+    def set_layout(self, slab_width: int = 0) -> None:
+        """HBM layout of the factor: -1 full square (8 N^2 B), > 0 column slabs of that width
+        (~4 N (N + W) B, what lets N = 262 144 fit one MI355X), 0 = automatic (default)."""
+        self._check(self._lib.bgp_set_layout(self._h, int(slab_width)), "bgp_set_layout")
+
+    def layout(self) -> tuple[int, int]:
+        """(slab width in use, 0 = full square; bytes of the factor buffer)."""
+        w, b = C.c_int64(0), C.c_int64(0)
+        self._lib.bgp_get_layout(self._h, C.byref(w), C.byref(b))
+        return int(w.value), int(b.value)
+
     # -- fit / predict ------------------------------------------------------------------------
     def _after_fit(self, lml, jit):
         self.lml = float(lml.value)

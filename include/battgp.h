@@ -89,6 +89,18 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
  *   lookahead        1 = overlap the next panel with the trailing update (default 1)     */
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
 
+/* HBM layout of the in-place covariance / Cholesky factor ("N_max per GPU", BASELINE.json metric).
+ *   slab_width = -1  full square [lda, Npad] column-major: 8 N^2 bytes (N_max ~ 196 000 on 288 GB)
+ *   slab_width >  0  column slabs of that width (multiple of nb_outer), each keeping only the rows
+ *                    from its own diagonal block down: ~4 N (N + slab_width) bytes - N = 262 144
+ *                    (BASELINE config 4's size) fits on ONE MI355X; results are bit-identical
+ *   slab_width =  0  (default) full square when it fits in free HBM, else the widest slab that does
+ * Changing the layout drops the resident problem.  bgp_get_layout reports the width in use by the
+ * resident problem (0 = full square) and the bytes of the factor buffer.  No reference call site
+ * (gpytorch keeps the dense square, README's "A1000 ceiling" N = 40 000). */
+int bgp_set_layout(bgp_handle* h, int64_t slab_width);
+int bgp_get_layout(const bgp_handle* h, int64_t* slab_width_out, int64_t* factor_bytes_out);
+
 /* FIT: upload (or adopt) X[N,D], y[N]; fill Sigma = K(X,X) + noise I in HBM; jittered
  * blocked Cholesky in place; z = L^-1 y; alpha = Sigma^-1 y; log-marginal likelihood
  *   lml = -1/2 y^T alpha - sum_i log L_ii - N/2 log 2 pi.
