@@ -24,6 +24,7 @@ SIGNATURES = {
     "bgp_last_error": (C.c_char_p, [handle_p]),
     "bgp_set_kernel": (C.c_int, [handle_p, C.c_int, c_double_p, C.c_int]),
     "bgp_set_options": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_double, C.c_int]),
+    "bgp_set_panel_scheme": (C.c_int, [handle_p, C.c_int]),
     "bgp_set_layout": (C.c_int, [handle_p, C.c_int64]),
     "bgp_get_layout": (C.c_int, [handle_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "bgp_fit": (C.c_int, [handle_p, c_double_p, c_double_p, C.c_int64, C.c_int, c_double_p, c_double_p]),

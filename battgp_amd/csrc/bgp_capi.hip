@@ -206,6 +206,26 @@ int check_info(bgp_handle* h, hipStream_t st, hipStream_t sp, int* dinfo, int* o
   return 0;
 }
 
+// workspaces of the diagonal-block panel scheme (panel_mode 1)
+int ensure_panel_ws(bgp_handle* h, int64_t nrows, int64_t NB) {
+  int64_t ldw = nrows;
+  if (ldw >= 2048 && (ldw % 512) == 0) ldw += 64;
+  if (h->nbw == NB && h->ldw >= ldw && h->dD) return 0;
+  dev_free(h, &h->dD, 2 * h->nbw * h->nbw);
+  dev_free(h, &h->dLinv, h->nbw * h->nbw);
+  dev_free(h, &h->dW[0], h->ldw * h->nbw);
+  dev_free(h, &h->dW[1], h->ldw * h->nbw);
+  h->nbw = h->ldw = 0;
+  int rc;
+  if ((rc = dev_alloc(h, &h->dD, 2 * NB * NB))) return rc;
+  h->nbw = NB;
+  if ((rc = dev_alloc(h, &h->dLinv, NB * NB))) return rc;
+  if ((rc = dev_alloc(h, &h->dW[0], ldw * NB))) return rc;
+  h->ldw = ldw;  // dev_free of dW[1] with a null pointer is a no-op
+  if ((rc = dev_alloc(h, &h->dW[1], ldw * NB))) return rc;
+  return 0;
+}
+
 // `nrows >= n`: rows n..nrows-1 are extra rows BELOW the square matrix (the augmented block whose
 // row n carries y^T): they ride through every TRSM / update like any other row below the
 // diagonal and come out as (L^-1 y)^T - the forward solve costs no launch of its own.
@@ -229,13 +249,28 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
     BGP_HIP(h, hipEventRecord(ev, st));
     BGP_HIP(h, hipStreamWaitEvent(sp, ev, 0));
   }
+  // Panel scheme (panel_mode 1): the latency-bound 64-wide chain {tile Cholesky, TRSM by the tile
+  // inverse, rank-64 update} runs only on the nbk x nbk diagonal block (copied to a workspace with an
+  // identity block riding below it, which comes out as L_kk^-T); the rows below - almost the whole
+  // panel - are then solved by ONE deep GEMM with the explicit triangular inverse, W = A21 L_kk^-T,
+  // into a compact workspace that the trailing updates read as their operand, and copied back into
+  // the matrix on a side stream.  24 launches over ~N/128 workgroups each -> 24 launches over <= 32
+  // workgroups + one MFMA-bound launch: the chain no longer queues for CU slots behind the trailing
+  // update, and the tall part runs at k = nbk instead of k = 64.
+  const bool dmode = h->panel_mode == 1 && nrows > NB;
+  if (dmode && (rc = ensure_panel_ws(h, nrows, NB))) return rc;
+  hipStream_t sc = h->s_copy;
+  const size_t EV_COPY = 4;  // ev_sync layout: 0 start, then per step {1 panel done, 2 rest done, 3 solve done, 4 copy done}
+  auto step_event = [&](int stp, size_t which, hipEvent_t* out) { return sync_event(h, which + EV_COPY * (size_t)stp, out); };
+  const double* Wcur = nullptr;  // solved rows below the diagonal block of the current panel (dmode)
+  int64_t Wrow0 = 0;
   // rank-nbk update of columns [c_begin, c_end) (all rows from the diagonal down + the extra rows) by
   // panel K0: one launch per slab
   auto update = [&](hipStream_t s, int tmode, int64_t K0, int64_t nbk, int64_t c_begin, int64_t c_end) -> int {
-    const int64_t ldp = V.ld(K0);
+    const int64_t ldp = dmode ? h->ldw : V.ld(K0);
     for (int64_t c_lo = c_begin; c_lo < c_end;) {
       const int64_t c_hi = V.slab_end(c_lo, c_end);
-      const double* P = V.at(c_lo, K0);
+      const double* P = dmode ? Wcur + (c_lo - Wrow0) : V.at(c_lo, K0);
       int r;
       if ((r = tt.begin(s))) return r;
       r = launch_gemm_nt(h, s, tmode, 128, V.at(c_lo, c_lo), V.ld(c_lo), P, ldp, P, ldp, (n - c_lo) + extra,
@@ -252,7 +287,32 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
     const int64_t K1 = K0 + nbk;
     const int64_t rows_trail = n - K1;
     const int64_t s0 = V.slab(K0) * V.W;  // origin of the panel's slab
-    if ((rc = factor_panel(h, sp, V.at(s0, s0), nrows - s0, V.ld(K0), inv, dinfo, K0 - s0, nbk, s0))) return rc;
+    if (!dmode) {
+      if ((rc = factor_panel(h, sp, V.at(s0, s0), nrows - s0, V.ld(K0), inv, dinfo, K0 - s0, nbk, s0))) return rc;
+    } else {
+      const int64_t ldk = V.ld(K0), ldd = 2 * NB;
+      double* Akk = V.at(K0, K0);
+      if ((rc = launch_diag_in(h, sp, Akk, ldk, h->dD, ldd, (int)nbk))) return rc;
+      if ((rc = factor_panel(h, sp, h->dD, 2 * nbk, ldd, inv, dinfo, 0, nbk, K0))) return rc;
+      if ((rc = launch_diag_out(h, sp, h->dD, ldd, Akk, ldk, h->dLinv, NB, (int)nbk))) return rc;
+      const int64_t rows_below = nrows - K1;
+      if (rows_below > 0) {
+        double* W = h->dW[step & 1];
+        // W[step & 1] was the operand of the updates of step - 2 (ordered before us on sp / through the
+        // look-ahead's wait for rest(step - 2)) and the source of its copy-back
+        if (step >= 2) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[4 + EV_COPY * (size_t)(step - 2)], 0));
+        rc = launch_gemm_nt(h, sp, 1, 64, W, h->ldw, V.at(K1, K0), ldk, h->dLinv, NB, rows_below, nbk, nbk, 0, dinfo, 1);
+        if (rc) return rc;
+        if ((rc = step_event(step, 3, &ev))) return rc;
+        BGP_HIP(h, hipEventRecord(ev, sp));
+        BGP_HIP(h, hipStreamWaitEvent(sc, ev, 0));
+        if ((rc = launch_copy_panel(h, sc, W, h->ldw, V.at(K1, K0), ldk, rows_below, (int)nbk))) return rc;
+        if ((rc = step_event(step, 4, &ev))) return rc;
+        BGP_HIP(h, hipEventRecord(ev, sc));
+        Wcur = W;
+        Wrow0 = K1;
+      }
+    }
     // deep rank-NB updates accumulate through L2 atomics (no C read in the tile prologue: +4 % at k = 512);
     // shallow ones keep the read-modify-write form (atomics lose below k ~ 256)
     const int tmode = (nbk >= 256 && h->lookahead != 3) ? 2 : 0;
@@ -263,19 +323,20 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
         const int64_t nbn = (rows_trail < NB) ? rows_trail : NB;  // width of the next panel
         const int64_t K2 = K1 + nbn;
         // panel(k) complete -> rest(k) may start on st
-        if ((rc = sync_event(h, 1 + 2 * (size_t)step, &ev))) return rc;
+        if ((rc = step_event(step, 1, &ev))) return rc;
         BGP_HIP(h, hipEventRecord(ev, sp));
         BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
         // la(k) on sp rewrites columns that rest(k-1) also updated: order it after rest(k-1)
-        if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + 2 * (size_t)(step - 1)], 0));
+        if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + EV_COPY * (size_t)(step - 1)], 0));
         if ((rc = update(sp, tmode, K0, nbk, K1, K2))) return rc;
         // rest(k) on st: everything right of the next panel
         if (n - K2 > 0 && (rc = update(st, tmode, K0, nbk, K2, n))) return rc;
-        if ((rc = sync_event(h, 2 + 2 * (size_t)step, &ev))) return rc;
+        if ((rc = step_event(step, 2, &ev))) return rc;
         BGP_HIP(h, hipEventRecord(ev, st));
       }
     }
   }
+  if (dmode) BGP_HIP(h, hipStreamSynchronize(sc));
   int info = 0;
   if ((rc = check_info(h, st, la ? sp : nullptr, dinfo, &info))) return rc;
   *info_out = info;
@@ -380,7 +441,8 @@ int choose_slab_width(bgp_handle* h, int64_t Npad, int64_t lda, int64_t* W_out) 
   }
   size_t free_b = 0, total_b = 0;
   BGP_HIP(h, hipMemGetInfo(&free_b, &total_b));
-  const double margin = 1.5e9;  // workspaces, query buffers, runtime
+  // workspaces (two solved-panel buffers of the panel scheme), query buffers, runtime
+  const double margin = 0.6e9 + (h->panel_mode == 1 ? 2.0 * (double)lda * (double)NB * 8.0 : 0.0);
   if ((double)lda * (double)Npad * 8.0 + margin <= (double)free_b) {
     *W_out = BGP_W_FULL;
     return 0;
@@ -662,10 +724,13 @@ int bgp_create(bgp_handle** out, int device) {
     }                                                                                    \
   } while (0)
   CREATE_HIP(hipSetDevice(device));
+  // A CU-masked main stream (hipExtStreamCreateWithCUMask, 1 or 8 CUs kept free for the panel stream)
+  // was measured 7 % SLOWER at N = 40 000 than plain streams: not used.
   CREATE_HIP(hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking));
   // default priority on purpose: on MI355X/ROCm 7.2 a high-priority stream was measured to get CU
   // slots LATER (99 us vs 12 us) than a default one next to a staggered big grid (tools/prio_probe.hip)
   CREATE_HIP(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
+  CREATE_HIP(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
   CREATE_HIP(hipEventCreate(&h->ev_a));
   CREATE_HIP(hipEventCreate(&h->ev_b));
   CREATE_HIP(hipEventCreate(&h->ev_c));
@@ -685,6 +750,10 @@ void bgp_destroy(bgp_handle* h) {
   if (h->s_main) (void)hipStreamSynchronize(h->s_main);
   free_problem(h);
   dev_free(h, &h->dXq, h->Xq_cap);
+  dev_free(h, &h->dD, 2 * h->nbw * h->nbw);
+  dev_free(h, &h->dLinv, h->nbw * h->nbw);
+  dev_free(h, &h->dW[0], h->ldw * h->nbw);
+  dev_free(h, &h->dW[1], h->ldw * h->nbw);
   dev_free(h, &h->dpart, h->part_cap);
   dev_free(h, &h->dout, h->out_cap);
   if (h->dscal) (void)hipFree(h->dscal);
@@ -699,6 +768,7 @@ void bgp_destroy(bgp_handle* h) {
   if (h->ev_d) (void)hipEventDestroy(h->ev_d);
   if (h->s_main) (void)hipStreamDestroy(h->s_main);
   if (h->s_aux) (void)hipStreamDestroy(h->s_aux);
+  if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
   delete h;
 }
 
@@ -730,6 +800,13 @@ int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, 
   if (max_tries >= 0) h->max_tries = max_tries;
   if (jitter0 >= 0.0) h->jitter0 = jitter0;
   if (lookahead >= 0) h->lookahead = lookahead;
+  return 0;
+}
+
+int bgp_set_panel_scheme(bgp_handle* h, int scheme) {
+  if (!h) return -1;
+  if (scheme != 0 && scheme != 1) return bgp_fail(h, -1, "bgp_set_panel_scheme: scheme must be 0 or 1");
+  h->panel_mode = scheme;
   return 0;
 }
 

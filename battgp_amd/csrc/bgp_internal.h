@@ -55,7 +55,7 @@ struct SlabView {
 
 struct bgp_handle {
   int device = 0;
-  hipStream_t s_main = nullptr, s_aux = nullptr;
+  hipStream_t s_main = nullptr, s_aux = nullptr, s_copy = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   std::vector<hipEvent_t> ev_pool;  // timing pairs around trailing updates
   std::vector<hipEvent_t> ev_sync;  // cross-stream dependencies of the look-ahead schedule
@@ -68,6 +68,7 @@ struct bgp_handle {
   int max_tries = 3;
   double jitter0 = 1e-8;
   int lookahead = 1;
+  int panel_mode = 1;    // 1: chain on the diagonal block + one deep TRSM-by-inverse GEMM; 0: 64-wide chain over all rows
   int64_t slab_req = 0;  // bgp_set_layout: 0 auto (full square if it fits, else slabs), -1 full square, > 0 width
   // problem
   int64_t N = 0, Npad = 0, lda = 0;
@@ -89,6 +90,11 @@ struct bgp_handle {
   double* dalpha = nullptr;  // [Npad]
   double* dB = nullptr;      // gradient workspace: U = L^-T (upper), [lda, Npad]; allocated on first bgp_lml_grad
   double* dS = nullptr;      // gradient workspace: S = -Sigma^-1 (lower), [lda, Npad]
+  // panel workspaces (panel_mode 1): diagonal block + riding identity, L_kk^-1, two solved-panel buffers
+  double* dD = nullptr;      // [2 nbw, nbw]
+  double* dLinv = nullptr;   // [nbw, nbw]
+  double* dW[2] = {nullptr, nullptr};  // [ldw, nbw] each
+  int64_t nbw = 0, ldw = 0;
   double* dE = nullptr;      // [lde, Npad] cross-covariance row block (queries x train)
   int64_t E_rows_cap = 0;
   double* dXq = nullptr;     // [M, D]
@@ -123,7 +129,12 @@ int launch_fill(bgp_handle* h, hipStream_t st, const FillParams& p, const double
                 int64_t nvalid1, int64_t nvalid2);
 int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, int64_t ldc,
                    const double* A, int64_t lda, const double* B, int64_t ldb, int64_t m, int64_t n,
-                   int64_t k, int lower, const int* abort_flag = nullptr);
+                   int64_t k, int lower, const int* abort_flag = nullptr, int btri = 0);
+int launch_diag_in(bgp_handle* h, hipStream_t st, const double* Akk, int64_t lda, double* D, int64_t ldd, int nbk);
+int launch_diag_out(bgp_handle* h, hipStream_t st, const double* D, int64_t ldd, double* Akk, int64_t lda,
+                    double* Linv, int64_t ldl, int nbk);
+int launch_copy_panel(bgp_handle* h, hipStream_t st, const double* src, int64_t lds_, double* dst, int64_t ldd,
+                      int64_t rows, int ncols);
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv,
                       int* info, int col0, int nvalid);
 int launch_fit_scalars(bgp_handle* h, hipStream_t st, const SlabView& A, const double* z,

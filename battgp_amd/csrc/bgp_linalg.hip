@@ -24,6 +24,13 @@ constexpr int BK = 16;  // k-depth of one LDS stage
 #define BGP_SUPER_LOG_SI 3  // super-tile = 2^SI x 2^(6-SI) tiles (64 per super-tile); 8 x 8 by default
 #endif
 __device__ __forceinline__ bool map_tile(int64_t b, int nti, int ntj, int lower, int& ti, int& tj) {
+  if (lower & 2) {
+    // small grids (the latency-bound panel kernels): one block per tile, no padding blocks that
+    // would each queue for a CU slot behind the trailing update
+    ti = (int)(b % nti);
+    tj = (int)(b / nti);
+    return tj < ntj && !((lower & 1) && ti < tj);
+  }
   constexpr int LSI = BGP_SUPER_LOG_SI, LSJ = 6 - BGP_SUPER_LOG_SI;
   constexpr int SI = 1 << LSI, SJ = 1 << LSJ;
   const int nsi = (nti + SI - 1) >> LSI;
@@ -103,7 +110,7 @@ template <int TM, int TN, int MODE, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc, const double* A,
                                                          int64_t lda, const double* B, int64_t ldb,
                                                          int64_t m, int64_t n, int k, int lower, int nti,
-                                                         int ntj, const int* __restrict__ abort_flag) {
+                                                         int ntj, const int* __restrict__ abort_flag, int btri) {
   constexpr int LDA_S = TM + 16;  // (ld % 32 == 16) => the two 16-lane groups of a ds_read_b64
   constexpr int LDB_S = TN + 16;  //  half-wave hit disjoint bank halves: conflict-free
   constexpr int MI = TM / 32, MJ = TN / 32;          // 16x16 MFMA tiles per wave along i / j
@@ -162,7 +169,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
 
   const int l15 = lane & 15, l4 = lane >> 4;
   const int ibase = wi * (TM / 2) + l15, jbase = wj * (TN / 2) + l15;
-  const int nk = k / BK;
+  // btri (TRSM by an explicit lower-triangular inverse, B[j, kk] = 0 for kk > j): columns j0..j0+TN-1 of
+  // the product only need kk < j0 + TN
+  const int nk = (MODE == 1 && btri && j0 + TN < k) ? (int)((j0 + TN) / BK) : k / BK;
   gload(0);
 
   // MODE 0: the accumulators START as the C tile and the B operand is staged negated, so the
@@ -569,11 +578,75 @@ __global__ __launch_bounds__(256) void copy_strided_kernel(const double* __restr
   if (i < npad) dst[i * ld] = (i < n) ? src[i] : 0.0;
 }
 
+// ---- panel factorisation through a workspace copy of the diagonal block -----------------------
+// D [2 nbk, nbk] (ld ldd): rows 0..nbk-1 = the diagonal block A_kk, rows nbk..2nbk-1 = identity.
+// The identity rides through the 64-wide chain like any rows below the diagonal and comes out as
+// L_kk^-T, from which diag_out writes Linv = L_kk^-1 (lower, row index contiguous) for the one deep
+// TRSM-by-inverse GEMM of the tall part of the panel.
+__global__ __launch_bounds__(256) void diag_in_kernel(const double* __restrict__ Akk, int64_t lda,
+                                                      double* __restrict__ D, int64_t ldd, int nbk) {
+  const int c = blockIdx.x;
+  for (int r = threadIdx.x; r < 2 * nbk; r += 256)
+    D[r + (int64_t)c * ldd] = (r < nbk) ? Akk[r + (int64_t)c * lda] : ((r - nbk == c) ? 1.0 : 0.0);
+}
+
+// Akk (lower triangle) <- L_kk;  Linv[j + kk ldl] = (L^-T)[kk, j] = D[nbk + kk, j]  (LDS-tiled transpose)
+__global__ __launch_bounds__(256) void diag_out_kernel(const double* __restrict__ D, int64_t ldd,
+                                                       double* __restrict__ Akk, int64_t lda,
+                                                       double* __restrict__ Linv, int64_t ldl, int nbk) {
+  __shared__ double t[64][65];
+  const int bi = blockIdx.x * 64, bj = blockIdx.y * 64;  // tile (rows bi.., cols bj..) of D / Akk
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if (bi >= bj) {
+    for (int cc = ty; cc < 64; cc += 4) {
+      const int r = bi + tx, c = bj + cc;
+      if (r >= c) Akk[r + (int64_t)c * lda] = D[r + (int64_t)c * ldd];
+    }
+  }
+  // R tile (rows kk = bi.., cols j = bj..) -> Linv tile (rows j = bj.., cols kk = bi..)
+  for (int cc = ty; cc < 64; cc += 4) t[cc][tx] = D[(nbk + bi + tx) + (int64_t)(bj + cc) * ldd];
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) Linv[(bj + tx) + (int64_t)(bi + cc) * ldl] = t[tx][cc];
+}
+
+// dst[r + c ldd] = src[r + c lds] for r < rows (even), c < ncols: copy-back of the solved panel
+__global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restrict__ src, int64_t lds_,
+                                                         double* __restrict__ dst, int64_t ldd, int64_t rows) {
+  const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (r >= rows) return;
+  const int64_t c = blockIdx.y;
+  *reinterpret_cast<double2*>(dst + r + c * ldd) = *reinterpret_cast<const double2*>(src + r + c * lds_);
+}
+
 }  // namespace
+
+int launch_diag_in(bgp_handle* h, hipStream_t st, const double* Akk, int64_t lda, double* D, int64_t ldd, int nbk) {
+  hipLaunchKernelGGL(diag_in_kernel, dim3((unsigned)nbk), dim3(256), 0, st, Akk, lda, D, ldd, nbk);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_diag_out(bgp_handle* h, hipStream_t st, const double* D, int64_t ldd, double* Akk, int64_t lda,
+                    double* Linv, int64_t ldl, int nbk) {
+  hipLaunchKernelGGL(diag_out_kernel, dim3((unsigned)(nbk / 64), (unsigned)(nbk / 64)), dim3(256), 0, st, D, ldd, Akk,
+                     lda, Linv, ldl, nbk);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_copy_panel(bgp_handle* h, hipStream_t st, const double* src, int64_t lds_, double* dst, int64_t ldd,
+                      int64_t rows, int ncols) {
+  if (rows <= 0 || ncols <= 0) return 0;
+  if ((rows & 1) || (lds_ & 1) || (ldd & 1)) return bgp_fail(h, -1, "copy_panel: rows and strides must be even");
+  hipLaunchKernelGGL(copy_panel_kernel, dim3((unsigned)((rows / 2 + 255) / 256), (unsigned)ncols), dim3(256), 0, st, src,
+                     lds_, dst, ldd, rows);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
 
 int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, int64_t ldc,
                    const double* A, int64_t lda, const double* B, int64_t ldb, int64_t m, int64_t n,
-                   int64_t k, int lower, const int* abort_flag) {
+                   int64_t k, int lower, const int* abort_flag, int btri) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   if ((k % BK) != 0) return bgp_fail(h, -1, "gemm_nt: k=%lld not a multiple of %d", (long long)k, BK);
   if ((m & 1) || (n & 1) || (lda & 1) || (ldb & 1))
@@ -583,21 +656,24 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
     return bgp_fail(h, -1, "gemm_nt: operands must be 16-byte aligned");
   const int TM = 128;
   const int nti = (int)((m + TM - 1) / TM), ntj = (int)((n + tn - 1) / tn);
-  const int64_t blocks = gemm_grid_blocks(nti, ntj, lower);
+  // up to one super-tile round per XCD of tiles: direct mapping (bit 1 of `lower`), exact grid
+  const bool small = (int64_t)nti * ntj <= 512;
+  if (small) lower |= 2;
+  const int64_t blocks = small ? (int64_t)nti * ntj : gemm_grid_blocks(nti, ntj, lower);
   if (blocks > 0x7fffffffLL) return bgp_fail(h, -1, "gemm_nt: grid too large");
   dim3 grid((unsigned)blocks), block(256);
   if (tn == 128 && mode == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj, abort_flag);
+                       (int)k, lower, nti, ntj, abort_flag, btri);
   else if (tn == 128 && mode == 2)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj, abort_flag);
+                       (int)k, lower, nti, ntj, abort_flag, btri);
   else if (tn == 64 && mode == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj, abort_flag);
+                       (int)k, lower, nti, ntj, abort_flag, btri);
   else if (tn == 64 && mode == 1)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj, abort_flag);
+                       (int)k, lower, nti, ntj, abort_flag, btri);
   else
     return bgp_fail(h, -1, "gemm_nt: unsupported variant tn=%d mode=%d", tn, mode);
   BGP_HIP(h, hipGetLastError());

@@ -94,6 +94,10 @@ class ExactGPEngine:
     def set_options(self, nb_outer=-1, max_tries=-1, jitter0=-1.0, lookahead=-1) -> None:
         self._check(self._lib.bgp_set_options(self._h, nb_outer, max_tries, jitter0, lookahead), "bgp_set_options")
 
+    def set_panel_scheme(self, scheme: int = 1) -> None:
+        """1 (default): critical chain on the diagonal block + one deep TRSM-by-inverse GEMM; 0: 64-wide chain over all rows."""
+        self._check(self._lib.bgp_set_panel_scheme(self._h, int(scheme)), "bgp_set_panel_scheme")
+
     def set_layout(self, slab_width: int = 0) -> None:
         """HBM layout of the factor: -1 full square (8 N^2 B), > 0 column slabs of that width
         (~4 N (N + W) B, what lets N = 262 144 fit one MI355X), 0 = automatic (default)."""

@@ -140,6 +140,7 @@ def main() -> None:
     ap.add_argument("--kernel", default="battgp", choices=["battgp", "matern32"])
     ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
     ap.add_argument("--lookahead", type=int, default=-1, help="0 = off, 1 = on + staggered first round (default), 2 = on, no stagger")
+    ap.add_argument("--panel-scheme", type=int, default=-1, help="0 = 64-wide chain over all rows, 1 = diagonal-block chain + one deep TRSM GEMM (default)")
     ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--separate", action="store_true", help="bgp_fit then bgp_predict (separate triangular-solve pass) instead of the fused call")
@@ -182,6 +183,8 @@ def main() -> None:
         eng.set_options(nb_outer=args.nb)
     if args.lookahead >= 0:
         eng.set_options(lookahead=args.lookahead)
+    if args.panel_scheme >= 0:
+        eng.set_panel_scheme(args.panel_scheme)
 
     def step():
         if args.separate:

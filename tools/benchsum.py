@@ -1,6 +1,6 @@
-"""Summarise bench.py JSON lines from stdin (diagnostic helper)."""
-import json, sys
-for line in sys.stdin:
+"""Summarise bench.py JSON lines from the files given (or stdin if none) - diagnostic helper."""
+import fileinput, json
+for line in fileinput.input():
     line = line.strip()
     if not line.startswith("{"):
         continue

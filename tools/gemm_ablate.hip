@@ -15,7 +15,7 @@ static void run(const char* name, double* C, double* A, int64_t ld, int64_t m, i
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 128, MODE, ABL>), dim3((unsigned)blocks), dim3(256), 0, 0, C, ld, A, ld, A, ld, m, n, k, 0, nti, ntj, (const int*)nullptr);
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 128, MODE, ABL>), dim3((unsigned)blocks), dim3(256), 0, 0, C, ld, A, ld, A, ld, m, n, k, 0, nti, ntj, (const int*)nullptr, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
   }
@@ -44,7 +44,7 @@ static void run_tn(const char* name, double* C, double* A, int64_t ld, int64_t m
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((gemm_nt_kernel<128, TN, 2, 0>), dim3((unsigned)blocks), dim3(256), 0, 0, C, ld, A, ld, A, ld, m, n, k, 0, nti, ntj, (const int*)nullptr);
+    hipLaunchKernelGGL((gemm_nt_kernel<128, TN, 2, 0>), dim3((unsigned)blocks), dim3(256), 0, 0, C, ld, A, ld, A, ld, m, n, k, 0, nti, ntj, (const int*)nullptr, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
   }

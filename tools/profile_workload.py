@@ -1,6 +1,6 @@
 """Workload for the rocprofv3 passes of tools/profile_round.sh: ONE fused fit+predict at N (the bench
 default's step) followed by alpha() - whose gemv_t_partial launches read the strictly-lower panels of L
-exactly once and calibrate FETCH_SIZE.   python tools/profile_workload.py 40000 [battgp|matern32]"""
+exactly once and calibrate FETCH_SIZE.   python tools/profile_workload.py 40000 [battgp|matern32] [reps]"""
 import json
 import os
 import sys
@@ -20,10 +20,13 @@ xq = synthetic.make_query(x, 300)
 tx, ty, tq = (torch.from_numpy(a).cuda() for a in (x, y, xq))
 torch.cuda.synchronize()
 eng = ExactGPEngine(kid, hyp, device=0)
+if os.environ.get("BGP_PANEL_SCHEME"):
+    eng.set_panel_scheme(int(os.environ["BGP_PANEL_SCHEME"]))
 tm = torch.empty(300, dtype=torch.float64, device="cuda")
 tv = torch.empty(300, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize()
-eng.fit_predict_device(tx.data_ptr(), ty.data_ptr(), n, 4, tq.data_ptr(), 300, tm.data_ptr(), tv.data_ptr())
+for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
+    eng.fit_predict_device(tx.data_ptr(), ty.data_ptr(), n, 4, tq.data_ptr(), 300, tm.data_ptr(), tv.data_ptr())
 mean = tm.cpu().numpy()
 ph = eng.phase_times()
 a = eng.alpha()
