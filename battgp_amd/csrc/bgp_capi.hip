@@ -183,6 +183,7 @@ struct TrailTimer {
       }
       h->times[BGP_T_TRAIL] = tot;
       h->times[BGP_T_TRAIL_FLOP] = flop;
+      h->times[BGP_T_TRAIL_LAUNCHES] = (double)(used / 2);
     }
     return 0;
   }
@@ -457,11 +458,17 @@ int choose_slab_width(bgp_handle* h, int64_t Npad, int64_t lda, int64_t* W_out) 
   return 0;
 }
 
+// measured on MI355X (bench.py --nb): N = 40 000: 344 ms at 1024 vs 348 ms at 512; N = 131 072: 10.71 s vs 10.91 s
+inline void apply_auto_nb(bgp_handle* h, int64_t n) {
+  if (h->nb_auto) h->nb_outer = n >= 32768 ? 1024 : 512;
+}
+
 int alloc_problem(bgp_handle* h, int64_t N, int D, int64_t Mride) {
   const int64_t aug_need = BGP_AUG + round_up(Mride, 64);
   if (h->N == N && h->D == D && h->dA && h->aug_cap >= aug_need) return 0;
   free_problem(h);
   const int64_t Npad = round_up(N, BGP_IB);
+  apply_auto_nb(h, Npad);
   // rows below the matrix: 64 for the augmented block (row Npad = y^T) + the query rows that ride
   // through the factorisation (bgp_fit_predict); avoid large power-of-two column strides (all
   // columns of a tile in one HBM channel)
@@ -796,6 +803,7 @@ int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, 
     if (nb_outer < 64 || (nb_outer % 64) != 0 || nb_outer > 2048)
       return bgp_fail(h, -1, "nb_outer must be a multiple of 64 in [64, 2048]");
     h->nb_outer = nb_outer;
+    h->nb_auto = false;
   }
   if (max_tries >= 0) h->max_tries = max_tries;
   if (jitter0 >= 0.0) h->jitter0 = jitter0;
@@ -1058,6 +1066,7 @@ int bgp_potrf_dev(bgp_handle* h, double* A_dev, int64_t n, int64_t lda, int* inf
     return bgp_fail(h, -1, "bgp_potrf_dev: n must be a positive multiple of 64, lda even and >= n");
   double* inv = nullptr;
   if ((rc = dev_alloc(h, &inv, n * BGP_IB))) return rc;
+  apply_auto_nb(h, n);
   int info = 0;
   {
     PhaseTimer t(h, h->s_main, BGP_T_POTRF);

@@ -65,6 +65,7 @@ struct bgp_handle {
   double hyp[BGP_MAX_HYP] = {0};
   // options
   int nb_outer = 512;
+  bool nb_auto = true;   // no explicit bgp_set_options(nb_outer): 1024 for Npad >= 32768 (deeper trailing updates), else 512
   int max_tries = 3;
   double jitter0 = 1e-8;
   int lookahead = 1;

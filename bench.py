@@ -72,6 +72,22 @@ def traffic_from_profile(n: int, kernel: str, key: str = "hbm_bytes_per_dispatch
         return json.load(f)["gemm_nt_128x128"].get(key)
 
 
+def n_max_from_profile():
+    """Largest N measured on one MI355X (column-slab layout of the factor, tools/large_n.py): the committed
+    record, not re-measured here (one fit at that size takes ~100 s)."""
+    path = os.path.join(ROOT, "profiles", "r01_large_n.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        runs = json.load(f)["runs"]
+    best = max(runs, key=lambda r: r["n"])
+    return {
+        "n": best["n"], "fit_predict_s": best["fit_predict_s"], "gflops": best["gflops"], "slab_width": best["slab_width"],
+        "factor_bytes": best["factor_bytes"], "residuals": best["residuals"], "full_square_limit_n": 196000,
+        "source": "profiles/r01_large_n.json (tools/large_n.py; not re-measured by this run)",
+    }
+
+
 def target_size_report(n: int, m: int) -> dict:
     """One fit+predict per kernel at the size the north-star targets are quoted on (N = 131 072):
     fill GB/s vs 8 TB/s, trailing-update TFLOP/s vs 78.6, and on-device residuals as correctness
@@ -279,8 +295,9 @@ def main() -> None:
             "residuals": {"rel_solve": resid[0], "max_llt": resid[1]} if resid else None,
             "mean_first": [float(v) for v in mean_host[:3]],
             "device_bytes": mem_bytes,
+            "n_max_per_gpu": n_max_from_profile(),
         }
-        out["roofline"]["launches_per_step"] = int(2 * max(0, -(-(((n + 63) // 64) * 64) // (args.nb if args.nb > 0 else 512)) - 1))
+        out["roofline"]["launches_per_step"] = int(round(avg["trail_launches"]))
         if world == 1 and args.target_n > 0 and args.target_n != n:
             out["target_size"] = target_size_report(args.target_n, m)
         if args.cpu_n > 0 and world == 1:

@@ -61,7 +61,8 @@ enum {
   BGP_T_TRAIL = 7,    /* sum of the outer trailing-update (MFMA SYRK) launches of the last potrf */
   BGP_T_TRAIL_FLOP = 8, /* algorithmic flop of those launches (2*m*n*k per full tile pair, lower half) */
   BGP_T_FILL_BYTES = 9, /* algorithmic bytes written by the last training fill */
-  BGP_T_COUNT = 10
+  BGP_T_TRAIL_LAUNCHES = 10, /* number of those trailing-update launches */
+  BGP_T_COUNT = 11
 };
 
 /* Library version (major*10000 + minor*100 + patch). */
@@ -83,7 +84,8 @@ const char* bgp_last_error(const bgp_handle* h);
 int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
 
 /* Tuning / numerical options.  Any argument < 0 (or NaN) keeps the current value.
- *   nb_outer         outer panel width of the blocked Cholesky (multiple of 64; default 512)
+ *   nb_outer         outer panel width of the blocked Cholesky (multiple of 64 in [64, 2048]; default: 512 below
+ *                    N = 32 768, 1024 from there on)
  *   max_tries        rungs of the jitter ladder after the plain attempt (default 3)
  *   jitter0          first rung (default 1e-8: linear_operator psd_safe_cholesky, fp64)
  *   lookahead        1 = overlap the next panel with the trailing update (default 1)     */

@@ -459,3 +459,51 @@ def test_allocation_failure_is_an_error_message():
     x, y = synthetic.make_cell_data(200)
     assert np.isfinite(e.fit(x, y))
     e.close()
+
+
+@pytest.mark.parametrize("kid", [K.KERNEL_BATTGP, K.KERNEL_MATERN32])
+@pytest.mark.parametrize("n,nb", [(700, 256), (2048, 512), (3001, 512), (5000, 1024), (4100, 2048)])
+def test_panel_schemes_agree_and_match_oracle(kid, n, nb):
+    """scheme 1 (chain on the diagonal block + one TRSM-by-explicit-inverse GEMM) against scheme 0 (64-wide
+    chain over all rows) and the oracle: same algebra, different rounding"""
+    hyp = synthetic.HYP_BATTGP if kid == K.KERNEL_BATTGP else synthetic.HYP_MATERN32
+    x, y = synthetic.make_cell_data(n, seed=n)
+    xq = synthetic.make_query(x, 200)
+    out = []
+    for scheme in (0, 1):
+        e = ExactGPEngine(kid, hyp)
+        e.set_options(nb_outer=nb)
+        e.set_panel_scheme(scheme)
+        lml, m, v = e.fit_predict(x, y, xq, min_var=-1.0)
+        m2, v2 = e.predict(xq, min_var=-1.0)
+        res = e.residuals(256)
+        e.close()
+        assert rel_err(m2, m) < 1e-8
+        assert res[0] < 1e-6 and res[1] < 1e-11, res
+        out.append((lml, m, v))
+    assert abs(out[0][0] - out[1][0]) <= 1e-9 * abs(out[0][0])
+    assert rel_err(out[1][1], out[0][1]) < 1e-8
+    gp = OracleGP(kid, hyp, x, y).fit()
+    m_ref, v_ref = gp.predict(xq, clamp=False)
+    assert abs(out[1][0] - gp.lml) <= REL * abs(gp.lml)
+    assert rel_err(out[1][1], m_ref) < REL
+    assert np.max(np.abs(out[1][2] - v_ref) / K.kernel_diag(kid, hyp, xq)) < 1e-9
+
+
+def test_default_panel_width_is_chosen_by_size():
+    """no explicit nb_outer: 512 below N = 32 768, 1024 from there on; results agree with an explicit 512"""
+    n = 33000
+    x, y = synthetic.make_cell_data(n)
+    xq = synthetic.make_query(x)
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    lml_auto, m_auto, _ = e.fit_predict(x, y, xq)
+    launches_auto = e.phase_times()["trail_launches"]
+    e.set_options(nb_outer=512)
+    lml_512, m_512, _ = e.fit_predict(x, y, xq)
+    launches_512 = e.phase_times()["trail_launches"]
+    r = e.residuals(256)
+    e.close()
+    assert launches_auto < 0.6 * launches_512
+    assert abs(lml_auto - lml_512) <= 1e-9 * abs(lml_512)
+    assert rel_err(m_auto, m_512) < 1e-8
+    assert r[0] < 1e-6 and r[1] < 1e-11
