@@ -323,13 +323,22 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
       } else {
         const int64_t nbn = (rows_trail < NB) ? rows_trail : NB;  // width of the next panel
         const int64_t K2 = K1 + nbn;
-        // panel(k) complete -> rest(k) may start on st
-        if ((rc = step_event(step, 1, &ev))) return rc;
-        BGP_HIP(h, hipEventRecord(ev, sp));
-        BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
+        // panel(k) complete -> rest(k) may start on st.  lookahead == 2: only after la(k) as well, so that
+        // la(k) has the GPU to itself for its few rounds and the next panel's chain starts earlier
+        const bool la_first = h->lookahead == 2;
+        if (!la_first) {
+          if ((rc = step_event(step, 1, &ev))) return rc;
+          BGP_HIP(h, hipEventRecord(ev, sp));
+          BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
+        }
         // la(k) on sp rewrites columns that rest(k-1) also updated: order it after rest(k-1)
         if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + EV_COPY * (size_t)(step - 1)], 0));
         if ((rc = update(sp, tmode, K0, nbk, K1, K2))) return rc;
+        if (la_first) {
+          if ((rc = step_event(step, 1, &ev))) return rc;
+          BGP_HIP(h, hipEventRecord(ev, sp));
+          BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
+        }
         // rest(k) on st: everything right of the next panel
         if (n - K2 > 0 && (rc = update(st, tmode, K0, nbk, K2, n))) return rc;
         if ((rc = step_event(step, 2, &ev))) return rc;

@@ -88,7 +88,9 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
  *                    N = 32 768, 1024 from there on)
  *   max_tries        rungs of the jitter ladder after the plain attempt (default 3)
  *   jitter0          first rung (default 1e-8: linear_operator psd_safe_cholesky, fp64)
- *   lookahead        1 = overlap the next panel with the trailing update (default 1)     */
+ *   lookahead        0 = off; 1 = the next panel is factorised underneath the trailing update (default);
+ *                    2 = same, with the update of the next panel's columns ordered before the rest (cleaner
+ *                    per-launch timings, ~1 % slower); 3 = 1 without the atomic-accumulate epilogue */
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
 
 /* Panel scheme of the blocked Cholesky (speed only; both are exact-Cholesky algebra).

@@ -16,7 +16,8 @@ import sys
 src, tag, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
 kname = sys.argv[4] if len(sys.argv) > 4 else "battgp"
 suffix = "" if kname == "battgp" else "_" + kname
-m, nb, simds, xccs = 300, 512, 1024, 8
+m, simds, xccs = 300, 1024, 8
+nb = 1024 if (n + 63) // 64 * 64 >= 32768 else 512  # the engine's default outer panel width (apply_auto_nb)
 
 
 def load(p):
