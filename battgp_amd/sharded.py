@@ -6,10 +6,11 @@ Distribution.  The matrix is cut into column panels of width ``nb``; panel ``j``
 ``j % world`` with ALL its rows from the diagonal down plus the 64-row augmented block whose row 0
 carries ``y^T``.  Right-looking factorisation, one exchange per panel step:
 
-    for k in panels:
-        owner(k):  factor panel k locally   (tile Cholesky + TRSM + in-panel updates: no communication)
-        broadcast  the packed factored panel  [(Npad + 64 - k nb) x nb]  from owner(k)        <- RCCL
-        every rank: C_j -= P[rows >= j nb] P[rows of j]^T  for each of ITS panels j > k       (MFMA)
+    for k in panels:                                   (panel k is already on every rank)
+        owner(k+1): C_{k+1} -= P_k ...; factor panel k+1 locally; pack it                     (look-ahead)
+        all ranks:  start the broadcast of packed panel k+1 [(Npad + 64 - (k+1) nb) x nb + flag]  <- RCCL, async
+        every rank: C_j -= P_k[rows >= j nb] P_k[rows of j]^T  for each of ITS panels j > k   (MFMA)
+        wait for the broadcast
 
 so each rank receives ~4 N^2 (w-1)/w bytes in total and runs 1/w of the N^3/3 flops.  The forward
 solve rides along in the augmented row (``z^T`` comes out of the factorisation), ``log det`` and the
@@ -245,14 +246,13 @@ class ShardedExactGP:
         self.store = be.empty(max(1, ncols_local) * ld)
         self.lcol0 = {j: lay.local_index(j) * lay.nb for j in mine}
         self.inv = {j: be.empty((lay.width(j) // 64) * 4096) for j in mine}
-        pbuf = be.empty(lay.nb * ld)
-        info_t = be.zeros(1)
+        pbufs = [be.empty(lay.nb * ld + 1), be.empty(lay.nb * ld + 1)]  # packed panel + failing-minor flag
 
         jitter = 0.0
         for attempt in range(self.max_tries + 1):
             for j in mine:
                 be.fill_panel(self.store, ld, self.lcol0[j], self.x_dev, n, d, lay.col0(j), lay.width(j), lay.rows_from(j), self.y_dev, jitter)
-            info = self._factor(pbuf, info_t)
+            info = self._factor(pbufs)
             if info == 0:
                 break
             if attempt == self.max_tries:
@@ -278,25 +278,54 @@ class ShardedExactGP:
         self.lml = -0.5 * zz - float(ld_t[0]) - 0.5 * n * math.log(2.0 * math.pi)
         return self.lml
 
-    def _factor(self, pbuf, info_t) -> int:
+    def _factor(self, pbufs) -> int:
+        """Right-looking factorisation with a one-panel look-ahead on the exchange: while every rank applies
+        panel k to its own panels, the owner of panel k+1 has already updated, factored and packed that
+        panel and its broadcast is in flight (``async_op``), so the xGMI transfer of panel k+1 hides behind
+        the rank-nb updates of step k.  ONE collective per step: the failing-minor flag travels as the
+        element behind the packed panel."""
         lay, be, ld = self.lay, self.be, self.lay.nrows
         mine = set(lay.local_panels(self.rank))
+
+        def factor_and_pack(k, buf):
+            c0, nbk, rows = lay.col0(k), lay.width(k), lay.rows_from(k)
+            info = be.factor_panel(self.store, ld, self.lcol0[k], c0, rows, nbk, self.inv[k])
+            if info == 0:
+                be.pack_panel(self.store, ld, self.lcol0[k], c0, rows, nbk, buf)
+            buf[nbk * rows] = float(info + c0 if info else 0)
+            be.after_comm()
+
+        def start_bcast(k, buf):
+            if self.dist is None:
+                return None
+            n_el = lay.width(k) * lay.rows_from(k) + 1
+            return self.dist.broadcast(self._t(buf[:n_el]), src=lay.owner(k), async_op=True)
+
+        if self.rank == lay.owner(0):
+            factor_and_pack(0, pbufs[0])
+        work = start_bcast(0, pbufs[0])
         for k in range(lay.npanels):
-            owner, c0, nbk, rows = lay.owner(k), lay.col0(k), lay.width(k), lay.rows_from(k)
-            if self.rank == owner:
-                info = be.factor_panel(self.store, ld, self.lcol0[k], c0, rows, nbk, self.inv[k])
-                info_t[0] = float(info + c0 if info else 0)
-                if info == 0:
-                    be.pack_panel(self.store, ld, self.lcol0[k], c0, rows, nbk, pbuf)
-            self._bcast(info_t, owner)
-            if float(info_t[0]) != 0.0:
-                return int(float(info_t[0]))
+            cur, nxt = pbufs[k % 2], pbufs[(k + 1) % 2]
+            c0, nbk, rows = lay.col0(k), lay.width(k), lay.rows_from(k)
+            if work is not None:
+                work.wait()
+                be.after_comm()
+            flag = float(cur[nbk * rows])
+            if flag != 0.0:
+                return int(flag)
             if k == lay.npanels - 1:
                 break
-            self._bcast(pbuf[: nbk * rows], owner)
-            for j in sorted(p for p in mine if p > k):
+            todo = sorted(p for p in mine if p > k)
+            if (k + 1) in mine:  # look-ahead: my next panel first, then factor and ship it
+                cj, nbj = lay.col0(k + 1), lay.width(k + 1)
+                be.update_panel(self.store, ld, self.lcol0[k + 1], cj, lay.rows_from(k + 1), nbj, cur, rows, cj - c0, nbk)
+                be.sync()
+                factor_and_pack(k + 1, nxt)
+                todo.remove(k + 1)
+            work = start_bcast(k + 1, nxt)
+            for j in todo:
                 cj, nbj = lay.col0(j), lay.width(j)
-                be.update_panel(self.store, ld, self.lcol0[j], cj, lay.rows_from(j), nbj, pbuf, rows, cj - c0, nbk)
+                be.update_panel(self.store, ld, self.lcol0[j], cj, lay.rows_from(j), nbj, cur, rows, cj - c0, nbk)
             be.sync()
         return 0
 
