@@ -1,7 +1,7 @@
 """One fit+predict at a size beyond the full-square ceiling (N > ~196 000 on 288 GB): the factor lives
 in column slabs (bgp_set_layout).  Prints one JSON line with timings, layout and on-device residuals.
 
-    python tools/large_n.py 262144 [battgp|matern32] [slab_width: 0 auto, -1 full square, >0 width] [m]
+    python tools/large_n.py 262144 [battgp|matern32] [slab_width: 0 auto, -1 full square, >0 width] [m] [nb_outer] [panel scheme]
 """
 import json
 import os
@@ -26,6 +26,11 @@ xq = synthetic.make_query(x, m)
 free0, total = torch.cuda.mem_get_info()
 eng = ExactGPEngine(kid, hyp, device=0)
 eng.set_layout(slab)
+nb = int(sys.argv[5]) if len(sys.argv) > 5 else -1
+if nb > 0:
+    eng.set_options(nb_outer=nb)
+if len(sys.argv) > 6:
+    eng.set_panel_scheme(int(sys.argv[6]))
 t0 = time.perf_counter()
 lml, mean, var = eng.fit_predict(x, y, xq)
 wall = time.perf_counter() - t0
@@ -34,7 +39,7 @@ width, fbytes = eng.layout()
 res = eng.residuals(256)
 flop = n**3 / 3.0 + float(n) * n * m + 2.0 * n * n
 out = {
-    "n": n, "m": m, "kernel": kernel, "slab_width": width, "factor_bytes": fbytes, "device_bytes": eng.device_bytes(),
+    "n": n, "m": m, "kernel": kernel, "nb_outer": nb if nb > 0 else "auto", "trail_launches": ph["trail_launches"], "slab_width": width, "factor_bytes": fbytes, "device_bytes": eng.device_bytes(),
     "hbm_total": total, "hbm_free_before": free0, "full_square_bytes": 8 * (n + 384) * n,
     "fit_predict_s": wall, "gflops": flop / wall / 1e9,
     "potrf_tflops": (n**3 / 3.0) / (ph["potrf_ms"] * 1e-3) / 1e12,
