@@ -80,7 +80,7 @@ def n_max_from_profile():
         return None
     with open(path) as f:
         runs = json.load(f)["runs"]
-    best = max(runs, key=lambda r: r["n"])
+    best = max(runs, key=lambda r: (r["n"], r.get("panel_scheme", 0)))
     return {
         "n": best["n"], "fit_predict_s": best["fit_predict_s"], "gflops": best["gflops"], "slab_width": best["slab_width"],
         "factor_bytes": best["factor_bytes"], "residuals": best["residuals"], "full_square_limit_n": 196000,
