@@ -238,7 +238,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   const int64_t extra = nrows - n;
   if (V.W < n && (V.W % NB) != 0)
     return bgp_fail(h, -1, "slab width %lld is not a multiple of nb_outer=%lld", (long long)V.W, (long long)NB);
-  const bool la = h->lookahead != 0 && n > 2 * NB;
+  const bool la = h->lookahead != 0 && n > NB;  // from two panels on
   hipStream_t sp = la ? h->s_aux : st;
   BGP_HIP(h, hipMemsetAsync(dinfo, 0, sizeof(int), st));
   TrailTimer tt{h, time_trailing};

@@ -271,13 +271,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
 }
 
 // ---- 64x64 diagonal tile: Cholesky + explicit inverse ------------------------------------
-// Register-resident: wave 0 holds the tile with lane = row, register = column (128 VGPRs) and
-// runs the right-looking column Cholesky with v_readlane broadcasts - no LDS traffic and no
-// barriers on the 64-step critical path.  Then 4 waves compute 16 columns each of X = L^-1 by
-// forward substitution in the same lane = row layout (4 waves x 16 columns: the kernel's footprint
-// - 4 waves, <= 256 VGPRs, 32 KB LDS - equals one GEMM workgroup, so it fits the half-CU slot a
-// finishing trailing-update workgroup frees and is not starved under look-ahead).  Fully unrolled: every register index
-// and every readlane lane-select is a compile-time constant.
+// Register-resident, 4 waves: lane = row, wave w owns columns 16w..16w+15 of the tile (32 VGPRs of
+// data).  Right-looking column Cholesky: the wave that owns column j scales it (v_readlane pivot, rsq +
+// Newton) and publishes it in a double-buffered 64-entry LDS column; after ONE barrier per step every
+// wave applies it to its own columns > j (uniform-address LDS reads broadcast L(c,j)).  The critical
+// path per step is {pivot, LDS write, barrier, LDS read, one FMA}: the 16-column updates of the other
+// waves run in its shadow (single-wave version: 36 us per tile, this one ~20 us).  Then X = L^-1 by
+// forward substitution in the same lane = row layout, columns dealt round-robin to the waves (column c
+// costs 64 - c steps).  Fully unrolled: every register index and readlane lane-select is a constant.
+// The arithmetic per element is the same sequence of FMAs as in the single-wave version.
 __device__ __forceinline__ double readlane_d(double v, int srclane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, srclane);
@@ -294,22 +296,66 @@ __device__ __forceinline__ double rsqrt_newton(double p) {
   return y;
 }
 
+// wave W: columns C0..C0+15 of the tile, s[c][r] = A(r, c) on entry and L(r, c) (zero above the
+// diagonal) on exit; every wave executes exactly 64 barriers, in three phases: (A) steps j < C0 update
+// all 16 columns, (B) the 16 steps that own the pivot column, (C) steps j >= C0 + 16 only keep the
+// barrier count
 template <int W>
-__device__ __forceinline__ void inv_slice(const double (*s)[64], double* __restrict__ inv, int lane) {
-  constexpr int NC = 16;  // columns per wave (4 waves)
-  constexpr int C0 = NC * W;
+__device__ __forceinline__ void chol_cols(double (*s)[64], double (*colbuf)[64], int* sfail, int lane) {
+  constexpr int NC = 16, C0 = NC * W;
+  double a[NC];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) a[cc] = s[C0 + cc][lane];
+  // (A) a rolled loop is fine here: every register index is static
+#pragma unroll 1
+  for (int j = 0; j < C0; ++j) {
+    __syncthreads();
+    const double* col = colbuf[j & 1];
+    const double lij = col[lane];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) a[cc] = __builtin_fma(-lij, col[C0 + cc], a[cc]);
+  }
+  // (B)
+#pragma unroll
+  for (int jl = 0; jl < NC; ++jl) {
+    const int j = C0 + jl;
+    const double piv = readlane_d(a[jl], j);
+    if (!(piv > 0.0) && lane == 0 && *sfail == 0) *sfail = j + 1;  // also catches NaN; first failing j wins
+    const double rd = rsqrt_newton(piv);
+    double d = piv * rd;
+    d = __builtin_fma(0.5 * rd, __builtin_fma(-d, d, piv), d);  // one correction: d = sqrt(piv)
+    const double lij = (lane > j) ? a[jl] * rd : 0.0;
+    a[jl] = (lane == j) ? d : lij;
+    colbuf[j & 1][lane] = lij;
+    __syncthreads();
+    // my own columns right of j: L(c, j) straight from the owner's registers (no LDS round trip on the
+    // critical path of the next pivot)
+#pragma unroll
+    for (int cc = jl + 1; cc < NC; ++cc) a[cc] = __builtin_fma(-lij, readlane_d(lij, C0 + cc), a[cc]);
+  }
+  // (C)
+#pragma unroll 1
+  for (int j = C0 + NC; j < 64; ++j) __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) s[C0 + cc][lane] = (C0 + cc <= lane) ? a[cc] : 0.0;
+}
+
+// wave W: columns W, W+4, ..., W+60 of X = L^-1
+template <int W>
+__device__ __forceinline__ void inv_cols(const double (*s)[64], double* __restrict__ inv, int lane) {
+  constexpr int NC = 16;
   const double rd_own = 1.0 / s[lane][lane];
   double x[NC];
 #pragma unroll
-  for (int cc = 0; cc < NC; ++cc) x[cc] = (lane == C0 + cc) ? 1.0 : 0.0;
+  for (int cc = 0; cc < NC; ++cc) x[cc] = (lane == W + 4 * cc) ? 1.0 : 0.0;
 #pragma unroll
-  for (int p = C0; p < 64; ++p) {
+  for (int p = W; p < 64; ++p) {
     const double rdp = readlane_d(rd_own, p);
     const double f = (lane == p) ? rdp : 1.0;
     const double lm = (lane == p) ? 0.0 : s[p][lane];  // L(lane, p); zero above the diagonal
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
-      if (C0 + cc <= p) {
+      if (W + 4 * cc <= p) {
         x[cc] *= f;                                // lane p: X(p,c) = acc_p / L_pp
         const double xpc = readlane_d(x[cc], p);
         x[cc] = __builtin_fma(-lm, xpc, x[cc]);    // rows below: acc_i -= L(i,p) X(p,c)
@@ -317,58 +363,43 @@ __device__ __forceinline__ void inv_slice(const double (*s)[64], double* __restr
     }
   }
 #pragma unroll
-  for (int cc = 0; cc < NC; ++cc) inv[lane + (C0 + cc) * 64] = x[cc];
+  for (int cc = 0; cc < NC; ++cc) inv[lane + (W + 4 * cc) * 64] = x[cc];
 }
 
 __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(double* __restrict__ Ajj, int64_t lda,
                                                             double* __restrict__ inv,
                                                             int* __restrict__ info, int col0) {
-  __shared__ double s[64][64];  // s[c][r] = A(r, c) on entry, L(r, c) (zero above the diagonal) after
+  __shared__ double s[64][64];      // s[c][r] = A(r, c) on entry, L(r, c) (zero above the diagonal) after
+  __shared__ double colbuf[2][64];  // the scaled pivot column of the current step
+  __shared__ int sfail;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (*info != 0) return;  // an earlier tile already failed: the whole pipeline is void
-  // coalesced tile load through LDS (also keeps 64 column addresses out of the VGPR budget)
+  if (tid == 0) sfail = 0;
+  // coalesced tile load through LDS.  The strict upper triangle holds don't-care values: they are
+  // updated like everything else but never read as a pivot or broadcast, so they cannot contaminate the factor.
   for (int idx = tid; idx < 4096; idx += 256) {
     const int r = idx & 63, c = idx >> 6;
     s[c][r] = Ajj[r + (int64_t)c * lda];
   }
   __syncthreads();
-  if (wave == 0) {
-    // The strict upper triangle holds don't-care values: they are updated like everything else
-    // but never read as a pivot or broadcast, so they cannot contaminate the factor.
-    double a[64];
-#pragma unroll
-    for (int c = 0; c < 64; ++c) a[c] = s[c][lane];
-    int fail = 0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const double piv = readlane_d(a[j], j);
-      if (!(piv > 0.0) && fail == 0) fail = j + 1;  // also catches NaN
-      const double rd = rsqrt_newton(piv);
-      double d = piv * rd;
-      d = __builtin_fma(0.5 * rd, __builtin_fma(-d, d, piv), d);  // one correction: d = sqrt(piv)
-      const double lij = (lane > j) ? a[j] * rd : 0.0;
-#pragma unroll
-      for (int c = j + 1; c < 64; ++c) {
-        const double lcj = readlane_d(lij, c);
-        a[c] = __builtin_fma(-lij, lcj, a[c]);
-      }
-      a[j] = (lane == j) ? d : lij;
-    }
-#pragma unroll
-    for (int c = 0; c < 64; ++c) s[c][lane] = (c <= lane) ? a[c] : 0.0;
-    if (lane == 0 && fail != 0) atomicCAS(info, 0, col0 + fail);
+  switch (wave) {
+    case 0: chol_cols<0>(s, colbuf, &sfail, lane); break;
+    case 1: chol_cols<1>(s, colbuf, &sfail, lane); break;
+    case 2: chol_cols<2>(s, colbuf, &sfail, lane); break;
+    default: chol_cols<3>(s, colbuf, &sfail, lane); break;
   }
   __syncthreads();
+  if (tid == 0 && sfail != 0) atomicCAS(info, 0, col0 + sfail);
   for (int idx = tid; idx < 4096; idx += 256) {
     const int r = idx & 63, c = idx >> 6;
     if (r >= c) Ajj[r + (int64_t)c * lda] = s[c][r];
   }
   switch (wave) {
-    case 0: inv_slice<0>(s, inv, lane); break;
-    case 1: inv_slice<1>(s, inv, lane); break;
-    case 2: inv_slice<2>(s, inv, lane); break;
-    default: inv_slice<3>(s, inv, lane); break;
+    case 0: inv_cols<0>(s, inv, lane); break;
+    case 1: inv_cols<1>(s, inv, lane); break;
+    case 2: inv_cols<2>(s, inv, lane); break;
+    default: inv_cols<3>(s, inv, lane); break;
   }
 }
 
@@ -488,16 +519,22 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ 
   const int64_t c0 = (int64_t)blockIdx.y * RD_COLS;
   const int64_t c1 = (c0 + RD_COLS < n) ? c0 + RD_COLS : n;
   if (mrow >= M) return;
-  double acc = 0.0;
-  if (vec) {
-    for (int64_t i = c0; i < c1; ++i) acc = __builtin_fma(E[mrow + i * lde], vec[i], acc);
-  } else {
-    for (int64_t i = c0; i < c1; ++i) {
-      const double e = E[mrow + i * lde];
-      acc = __builtin_fma(e, e, acc);
+  // 8 independent partial sums: the loads of 8 columns are in flight together (one dependent chain of
+  // 512 global loads made this kernel 90 us at N = 2048)
+  double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int64_t i = c0;
+  for (; i + 8 <= c1; i += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double e = E[mrow + (i + u) * lde];
+      a8[u] = __builtin_fma(e, vec ? vec[i + u] : e, a8[u]);
     }
   }
-  part[(int64_t)blockIdx.y * M + mrow] = acc;
+  for (; i < c1; ++i) {
+    const double e = E[mrow + i * lde];
+    a8[0] = __builtin_fma(e, vec ? vec[i] : e, a8[0]);
+  }
+  part[(int64_t)blockIdx.y * M + mrow] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
 }
 
 // mean:  out[m] = sum_chunks part         (kdiag == 0)
