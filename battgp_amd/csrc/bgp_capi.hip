@@ -208,22 +208,35 @@ int check_info(bgp_handle* h, hipStream_t st, hipStream_t sp, int* dinfo, int* o
 }
 
 // workspaces of the diagonal-block panel scheme (panel_mode 1)
-int ensure_panel_ws(bgp_handle* h, int64_t nrows, int64_t NB) {
-  int64_t ldw = nrows;
-  if (ldw >= 2048 && (ldw % 512) == 0) ldw += 64;
-  if (h->nbw == NB && h->ldw >= ldw && h->dD) return 0;
+void free_panel_ws(bgp_handle* h) {
   dev_free(h, &h->dD, 2 * h->nbw * h->nbw);
   dev_free(h, &h->dLinv, h->nbw * h->nbw);
   dev_free(h, &h->dW[0], h->ldw * h->nbw);
   dev_free(h, &h->dW[1], h->ldw * h->nbw);
   h->nbw = h->ldw = 0;
+}
+
+int ensure_panel_ws(bgp_handle* h, int64_t nrows, int64_t NB) {
+  int64_t ldw = nrows;
+  if (ldw >= 2048 && (ldw % 512) == 0) ldw += 64;
+  if (h->nbw == NB && h->ldw >= ldw) return 0;  // nbw / ldw are only set once all four buffers exist
+  free_panel_ws(h);
+  double *d = nullptr, *li = nullptr, *w0 = nullptr, *w1 = nullptr;
   int rc;
-  if ((rc = dev_alloc(h, &h->dD, 2 * NB * NB))) return rc;
+  if ((rc = dev_alloc(h, &d, 2 * NB * NB)) || (rc = dev_alloc(h, &li, NB * NB)) || (rc = dev_alloc(h, &w0, ldw * NB)) ||
+      (rc = dev_alloc(h, &w1, ldw * NB))) {
+    dev_free(h, &d, 2 * NB * NB);
+    dev_free(h, &li, NB * NB);
+    dev_free(h, &w0, ldw * NB);
+    dev_free(h, &w1, ldw * NB);
+    return rc;
+  }
+  h->dD = d;
+  h->dLinv = li;
+  h->dW[0] = w0;
+  h->dW[1] = w1;
   h->nbw = NB;
-  if ((rc = dev_alloc(h, &h->dLinv, NB * NB))) return rc;
-  if ((rc = dev_alloc(h, &h->dW[0], ldw * NB))) return rc;
-  h->ldw = ldw;  // dev_free of dW[1] with a null pointer is a no-op
-  if ((rc = dev_alloc(h, &h->dW[1], ldw * NB))) return rc;
+  h->ldw = ldw;
   return 0;
 }
 
@@ -766,10 +779,7 @@ void bgp_destroy(bgp_handle* h) {
   if (h->s_main) (void)hipStreamSynchronize(h->s_main);
   free_problem(h);
   dev_free(h, &h->dXq, h->Xq_cap);
-  dev_free(h, &h->dD, 2 * h->nbw * h->nbw);
-  dev_free(h, &h->dLinv, h->nbw * h->nbw);
-  dev_free(h, &h->dW[0], h->ldw * h->nbw);
-  dev_free(h, &h->dW[1], h->ldw * h->nbw);
+  free_panel_ws(h);
   dev_free(h, &h->dpart, h->part_cap);
   dev_free(h, &h->dout, h->out_cap);
   if (h->dscal) (void)hipFree(h->dscal);

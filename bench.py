@@ -50,7 +50,14 @@ def cpu_baseline(kernel_id, hyp, n_cpu: int, m: int, seed: int):
     gp.predict(xq)
     dt = time.perf_counter() - t0
     threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    # BASELINE configs[0] (N = 2048, the reference's own CPU-runnable case) beside it
+    x0, y0 = synthetic.make_cell_data(2048, seed=2048)
+    xq0 = synthetic.make_query(x0, m)
+    t0 = time.perf_counter()
+    OracleGP(kernel_id, hyp, x0, y0).fit().predict(xq0)
+    dt0 = time.perf_counter() - t0
     return {
+        "config0_n2048": {"seconds": dt0, "value": algorithmic_flop(2048, m) / dt0 / 1e9},
         "value": algorithmic_flop(n_cpu, m) / dt / 1e9,
         "unit": "GFLOP/s",
         "cores": int(threads),
