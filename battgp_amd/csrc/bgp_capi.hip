@@ -118,13 +118,9 @@ struct PhaseTimer {
 //  inverse (MFMA), rank-64 update of the rest of the panel (MFMA)}; then one rank-NB SYRK
 //  update of the whole trailing matrix (MFMA) - the kernel that carries ~all the flops.
 //
-//  Look-ahead (h->lookahead): the trailing update of panel k is split into the columns of
-//  panel k+1 ("la", on the panel stream sp) and the rest ("rest", on the main stream st), so
-//  that the latency-bound factorisation of panel k+1 runs on sp underneath rest(k):
-//      sp: panel(0) la(0) panel(1) [wait rest(0)] la(1) panel(2) [wait rest(1)] la(2) ...
-//      st:          [wait panel(0)] rest(0) [wait panel(1)] rest(1) ...
-//  Every element still receives exactly the same single rank-NB update, so the factor is
-//  bit-identical with and without look-ahead.
+//  Look-ahead (h->lookahead, see potrf_driver): the panel stream factors panel k+1 underneath the main
+//  stream's trailing update by panel k.  Every element still receives exactly the same rank-NB updates in
+//  panel order, so the factor is bit-identical with and without look-ahead.
 // `A` is the origin of the panel's slab (or of a stand-alone panel), K0 the panel's first column
 // relative to it and `gofs` the global index of that origin (tile inverses and the failing-minor
 // report are indexed globally).
@@ -211,32 +207,33 @@ int check_info(bgp_handle* h, hipStream_t st, hipStream_t sp, int* dinfo, int* o
 void free_panel_ws(bgp_handle* h) {
   dev_free(h, &h->dD, 2 * h->nbw * h->nbw);
   dev_free(h, &h->dLinv, h->nbw * h->nbw);
-  dev_free(h, &h->dW[0], h->ldw * h->nbw);
-  dev_free(h, &h->dW[1], h->ldw * h->nbw);
+  for (int b = 0; b < BGP_MAX_WBUF; ++b) dev_free(h, &h->dW[b], h->ldw * h->nbw);
   h->nbw = h->ldw = 0;
+  h->nwbuf = 0;
 }
 
-int ensure_panel_ws(bgp_handle* h, int64_t nrows, int64_t NB) {
+int ensure_panel_ws(bgp_handle* h, int64_t nrows, int64_t NB, int nbuf) {
   int64_t ldw = nrows;
   if (ldw >= 2048 && (ldw % 512) == 0) ldw += 64;
-  if (h->nbw == NB && h->ldw >= ldw) return 0;  // nbw / ldw are only set once all four buffers exist
+  // nbw / ldw / nwbuf are only set once all buffers exist
+  if (h->nbw == NB && h->ldw >= ldw && h->nwbuf >= nbuf) return 0;
   free_panel_ws(h);
-  double *d = nullptr, *li = nullptr, *w0 = nullptr, *w1 = nullptr;
-  int rc;
-  if ((rc = dev_alloc(h, &d, 2 * NB * NB)) || (rc = dev_alloc(h, &li, NB * NB)) || (rc = dev_alloc(h, &w0, ldw * NB)) ||
-      (rc = dev_alloc(h, &w1, ldw * NB))) {
+  double *d = nullptr, *li = nullptr, *w[BGP_MAX_WBUF] = {nullptr};
+  int rc = dev_alloc(h, &d, 2 * NB * NB);
+  if (!rc) rc = dev_alloc(h, &li, NB * NB);
+  for (int b = 0; b < nbuf && !rc; ++b) rc = dev_alloc(h, &w[b], ldw * NB);
+  if (rc) {
     dev_free(h, &d, 2 * NB * NB);
     dev_free(h, &li, NB * NB);
-    dev_free(h, &w0, ldw * NB);
-    dev_free(h, &w1, ldw * NB);
+    for (int b = 0; b < nbuf; ++b) dev_free(h, &w[b], ldw * NB);
     return rc;
   }
   h->dD = d;
   h->dLinv = li;
-  h->dW[0] = w0;
-  h->dW[1] = w1;
+  for (int b = 0; b < nbuf; ++b) h->dW[b] = w[b];
   h->nbw = NB;
   h->ldw = ldw;
+  h->nwbuf = nbuf;
   return 0;
 }
 
@@ -251,7 +248,12 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   const int64_t extra = nrows - n;
   if (V.W < n && (V.W % NB) != 0)
     return bgp_fail(h, -1, "slab width %lld is not a multiple of nb_outer=%lld", (long long)V.W, (long long)NB);
-  const bool la = h->lookahead != 0 && n > NB;  // from two panels on
+  // lookahead: bits 0-2 = depth d (0 = off), bit 3 = order the panel stream's updates before rest(k),
+  // bit 4 = no atomic-accumulate epilogue (ablation)
+  const int depth_req = h->lookahead & 7;
+  const bool la = depth_req != 0 && n > NB;  // from two panels on
+  const int depth = la ? (depth_req > BGP_MAX_WBUF - 1 ? BGP_MAX_WBUF - 1 : depth_req) : 0;
+  const bool la_first = (h->lookahead & 8) != 0;
   hipStream_t sp = la ? h->s_aux : st;
   BGP_HIP(h, hipMemsetAsync(dinfo, 0, sizeof(int), st));
   TrailTimer tt{h, time_trailing};
@@ -272,35 +274,49 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   // workgroups + one MFMA-bound launch: the chain no longer queues for CU slots behind the trailing
   // update, and the tall part runs at k = nbk instead of k = 64.
   const bool dmode = h->panel_mode == 1 && nrows > NB;
-  if (dmode && (rc = ensure_panel_ws(h, nrows, NB))) return rc;
+  const int nbuf = depth + 1;  // solved-panel buffers alive at once: the sources of the next panel + the one being written
+  if (dmode && (rc = ensure_panel_ws(h, nrows, NB, nbuf))) return rc;
   hipStream_t sc = h->s_copy;
   const size_t EV_COPY = 4;  // ev_sync layout: 0 start, then per step {1 panel done, 2 rest done, 3 solve done, 4 copy done}
   auto step_event = [&](int stp, size_t which, hipEvent_t* out) { return sync_event(h, which + EV_COPY * (size_t)stp, out); };
-  const double* Wcur = nullptr;  // solved rows below the diagonal block of the current panel (dmode)
-  int64_t Wrow0 = 0;
+  struct Src {  // a factored panel as the operand of later updates
+    int64_t K0, nbk, K1;
+    const double* W;  // dmode: solved rows below the diagonal block, row 0 = global row K1
+  };
+  std::vector<Src> src;
   // rank-nbk update of columns [c_begin, c_end) (all rows from the diagonal down + the extra rows) by
-  // panel K0: one launch per slab
-  auto update = [&](hipStream_t s, int tmode, int64_t K0, int64_t nbk, int64_t c_begin, int64_t c_end) -> int {
-    const int64_t ldp = dmode ? h->ldw : V.ld(K0);
+  // panel `p`: one launch per slab
+  auto update = [&](hipStream_t s, int tmode, const Src& p, int64_t c_begin, int64_t c_end) -> int {
+    const int64_t ldp = dmode ? h->ldw : V.ld(p.K0);
     for (int64_t c_lo = c_begin; c_lo < c_end;) {
       const int64_t c_hi = V.slab_end(c_lo, c_end);
-      const double* P = dmode ? Wcur + (c_lo - Wrow0) : V.at(c_lo, K0);
+      const double* P = dmode ? p.W + (c_lo - p.K1) : V.at(c_lo, p.K0);
       int r;
       if ((r = tt.begin(s))) return r;
       r = launch_gemm_nt(h, s, tmode, 128, V.at(c_lo, c_lo), V.ld(c_lo), P, ldp, P, ldp, (n - c_lo) + extra,
-                         c_hi - c_lo, nbk, 1, dinfo);
+                         c_hi - c_lo, p.nbk, 1, dinfo);
       if (r) return r;
-      if ((r = tt.end(s, (double)(n - c_lo), (double)(c_hi - c_lo), (double)nbk))) return r;
+      if ((r = tt.end(s, (double)(n - c_lo), (double)(c_hi - c_lo), (double)p.nbk))) return r;
       c_lo = c_hi;
     }
     return 0;
   };
+  // deep rank-NB updates accumulate through L2 atomics (no C read in the tile prologue: +4 % at k = 512);
+  // shallow ones keep the read-modify-write form (atomics lose below k ~ 256)
+  auto tmode_of = [&](int64_t nbk) { return (nbk >= 256 && !(h->lookahead & 16)) ? 2 : 0; };
+  // Look-ahead of depth d.  Panel stream sp, iteration k:  chain(k), then the LEFT-LOOKING update of
+  // panel k+1 by the last d factored panels k+1-d .. k (in that order - every element still receives
+  // its rank-NB updates in panel order, so the factor is bit-identical for every d), the first of which
+  // must wait for rest(k-d), the last writer of those columns on the main stream.  Main stream st:
+  // rest(k) = update of the panels >= k+d+1 by panel k, as soon as panel k is factored.  chain(k+1)
+  // therefore only waits for rest(k-d): the latency-bound chain has d trailing updates to hide behind.
   int step = 0;
   for (int64_t K0 = 0; K0 < n; K0 += NB, ++step) {
     const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
     const int64_t K1 = K0 + nbk;
     const int64_t rows_trail = n - K1;
     const int64_t s0 = V.slab(K0) * V.W;  // origin of the panel's slab
+    const double* Wk = nullptr;
     if (!dmode) {
       if ((rc = factor_panel(h, sp, V.at(s0, s0), nrows - s0, V.ld(K0), inv, dinfo, K0 - s0, nbk, s0))) return rc;
     } else {
@@ -311,10 +327,10 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
       if ((rc = launch_diag_out(h, sp, h->dD, ldd, Akk, ldk, h->dLinv, NB, (int)nbk))) return rc;
       const int64_t rows_below = nrows - K1;
       if (rows_below > 0) {
-        double* W = h->dW[step & 1];
-        // W[step & 1] was the operand of the updates of step - 2 (ordered before us on sp / through the
-        // look-ahead's wait for rest(step - 2)) and the source of its copy-back
-        if (step >= 2) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[4 + EV_COPY * (size_t)(step - 2)], 0));
+        double* W = h->dW[step % nbuf];
+        // W[step % nbuf] was the operand of panel step - nbuf: its updates on sp are ordered before us, its
+        // rest() finished before the sp updates of the previous iteration started, its copy-back is waited for
+        if (step >= nbuf) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[4 + EV_COPY * (size_t)(step - nbuf)], 0));
         rc = launch_gemm_nt(h, sp, 1, 64, W, h->ldw, V.at(K1, K0), ldk, h->dLinv, NB, rows_below, nbk, nbk, 0, dinfo, 1);
         if (rc) return rc;
         if ((rc = step_event(step, 3, &ev))) return rc;
@@ -323,41 +339,36 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
         if ((rc = launch_copy_panel(h, sc, W, h->ldw, V.at(K1, K0), ldk, rows_below, (int)nbk))) return rc;
         if ((rc = step_event(step, 4, &ev))) return rc;
         BGP_HIP(h, hipEventRecord(ev, sc));
-        Wcur = W;
-        Wrow0 = K1;
+        Wk = W;
       }
     }
-    // deep rank-NB updates accumulate through L2 atomics (no C read in the tile prologue: +4 % at k = 512);
-    // shallow ones keep the read-modify-write form (atomics lose below k ~ 256)
-    const int tmode = (nbk >= 256 && h->lookahead != 3) ? 2 : 0;
-    if (rows_trail > 0) {
-      if (!la) {
-        if ((rc = update(st, tmode, K0, nbk, K1, n))) return rc;
-      } else {
-        const int64_t nbn = (rows_trail < NB) ? rows_trail : NB;  // width of the next panel
-        const int64_t K2 = K1 + nbn;
-        // panel(k) complete -> rest(k) may start on st.  lookahead == 2: only after la(k) as well, so that
-        // la(k) has the GPU to itself for its few rounds and the next panel's chain starts earlier
-        const bool la_first = h->lookahead == 2;
-        if (!la_first) {
-          if ((rc = step_event(step, 1, &ev))) return rc;
-          BGP_HIP(h, hipEventRecord(ev, sp));
-          BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
-        }
-        // la(k) on sp rewrites columns that rest(k-1) also updated: order it after rest(k-1)
-        if (step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + EV_COPY * (size_t)(step - 1)], 0));
-        if ((rc = update(sp, tmode, K0, nbk, K1, K2))) return rc;
-        if (la_first) {
-          if ((rc = step_event(step, 1, &ev))) return rc;
-          BGP_HIP(h, hipEventRecord(ev, sp));
-          BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
-        }
-        // rest(k) on st: everything right of the next panel
-        if (n - K2 > 0 && (rc = update(st, tmode, K0, nbk, K2, n))) return rc;
-        if ((rc = step_event(step, 2, &ev))) return rc;
-        BGP_HIP(h, hipEventRecord(ev, st));
-      }
+    src.push_back(Src{K0, nbk, K1, Wk});
+    if (rows_trail <= 0) continue;
+    if (!la) {
+      if ((rc = update(st, tmode_of(nbk), src[step], K1, n))) return rc;
+      continue;
     }
+    const int64_t nbn = (rows_trail < NB) ? rows_trail : NB;  // width of the next panel
+    const int64_t K2 = K1 + nbn;
+    if (!la_first) {  // panel(k) complete -> rest(k) may start on st
+      if ((rc = step_event(step, 1, &ev))) return rc;
+      BGP_HIP(h, hipEventRecord(ev, sp));
+      BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
+    }
+    // the next panel's columns were last written on st by rest(k-d)
+    if (step - depth >= 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + EV_COPY * (size_t)(step - depth)], 0));
+    for (int sidx = (step + 1 - depth > 0) ? step + 1 - depth : 0; sidx <= step; ++sidx)
+      if ((rc = update(sp, tmode_of(src[sidx].nbk), src[sidx], K1, K2))) return rc;
+    if (la_first) {  // ... or only after the panel stream's updates (per-launch timings do not overlap)
+      if ((rc = step_event(step, 1, &ev))) return rc;
+      BGP_HIP(h, hipEventRecord(ev, sp));
+      BGP_HIP(h, hipStreamWaitEvent(st, ev, 0));
+    }
+    // rest(k) on st: the panels from k+d+1 on
+    const int64_t cr = K1 + (int64_t)depth * NB;
+    if (cr < n && (rc = update(st, tmode_of(nbk), src[step], cr, n))) return rc;
+    if ((rc = step_event(step, 2, &ev))) return rc;
+    BGP_HIP(h, hipEventRecord(ev, st));
   }
   if (dmode) BGP_HIP(h, hipStreamSynchronize(sc));
   int info = 0;
@@ -465,7 +476,7 @@ int choose_slab_width(bgp_handle* h, int64_t Npad, int64_t lda, int64_t* W_out) 
   size_t free_b = 0, total_b = 0;
   BGP_HIP(h, hipMemGetInfo(&free_b, &total_b));
   // workspaces (two solved-panel buffers of the panel scheme), query buffers, runtime
-  const double margin = 0.6e9 + (h->panel_mode == 1 ? 2.0 * (double)lda * (double)NB * 8.0 : 0.0);
+  const double margin = 0.6e9 + (h->panel_mode == 1 ? ((h->lookahead & 7) + 1.0) * (double)lda * (double)NB * 8.0 : 0.0);
   if ((double)lda * (double)Npad * 8.0 + margin <= (double)free_b) {
     *W_out = BGP_W_FULL;
     return 0;

@@ -10,6 +10,7 @@
 #include "../../include/battgp.h"
 
 #define BGP_IB 64  // inner (diagonal tile) block of the Cholesky; also the K-granule of the path
+#define BGP_MAX_WBUF 5  // solved-panel workspaces (look-ahead depth <= 4)
 #define BGP_AUG 64 // rows of the augmented block below the matrix (row 0 of it carries y^T)
 
 struct FillParams {
@@ -94,8 +95,9 @@ struct bgp_handle {
   // panel workspaces (panel_mode 1): diagonal block + riding identity, L_kk^-1, two solved-panel buffers
   double* dD = nullptr;      // [2 nbw, nbw]
   double* dLinv = nullptr;   // [nbw, nbw]
-  double* dW[2] = {nullptr, nullptr};  // [ldw, nbw] each
+  double* dW[BGP_MAX_WBUF] = {nullptr};  // [ldw, nbw] each; look-ahead depth + 1 of them in use
   int64_t nbw = 0, ldw = 0;
+  int nwbuf = 0;
   double* dE = nullptr;      // [lde, Npad] cross-covariance row block (queries x train)
   int64_t E_rows_cap = 0;
   double* dXq = nullptr;     // [M, D]

@@ -162,7 +162,7 @@ def main() -> None:
     ap.add_argument("--m", type=int, default=300, help="query points (battgp_full.py:98)")
     ap.add_argument("--kernel", default="battgp", choices=["battgp", "matern32"])
     ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
-    ap.add_argument("--lookahead", type=int, default=-1, help="0 = off, 1 = next panel overlaps the trailing update (default), 2 = same with la(k) ordered before rest(k)")
+    ap.add_argument("--lookahead", type=int, default=-1, help="bits 0-2: look-ahead depth (0 off, 1 default); +8: panel-stream updates ordered before rest(k); +16: no atomic epilogue")
     ap.add_argument("--panel-scheme", type=int, default=-1, help="0 = 64-wide chain over all rows, 1 = diagonal-block chain + one deep TRSM GEMM (default)")
     ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
@@ -234,10 +234,10 @@ def main() -> None:
 
     # The la(k) and rest(k) launches of a panel overlap each other in the default schedule (fastest wall
     # clock), which stretches both event-timed durations.  One extra, untimed step with la(k) ordered before
-    # rest(k) (lookahead = 2, ~1 % slower overall) gives the kernel's own rate per launch.
+    # rest(k) (lookahead = 1 | 8, ~1 % slower overall) gives the kernel's own rate per launch.
     serial = None
     if args.lookahead < 0:
-        eng.set_options(lookahead=2)
+        eng.set_options(lookahead=1 | 8)
         step()
         ph2 = eng.phase_times()
         serial = ph2["trail_flop"] / (ph2["trail_ms"] * 1e-3) / 1e12 if ph2["trail_ms"] > 0 else None

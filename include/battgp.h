@@ -88,9 +88,12 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
  *                    N = 32 768, 1024 from there on)
  *   max_tries        rungs of the jitter ladder after the plain attempt (default 3)
  *   jitter0          first rung (default 1e-8: linear_operator psd_safe_cholesky, fp64)
- *   lookahead        0 = off; 1 = the next panel is factorised underneath the trailing update (default);
- *                    2 = same, with the update of the next panel's columns ordered before the rest (cleaner
- *                    per-launch timings, ~1 % slower); 3 = 1 without the atomic-accumulate epilogue */
+ *   lookahead        bits 0-2: depth d of the look-ahead (0 = off, default 1, <= 4): the panel stream factors
+ *                    panel k+1 and updates it left-looking from the last d panels while the main stream
+ *                    applies panel k to the panels from k+d+1 on (d > 1 measured slower: the panel stream is
+ *                    the critical path); +8: the panel stream's updates are ordered before the main
+ *                    stream's (per-launch timings do not overlap, ~1 % slower); +16: trailing updates
+ *                    without the atomic-accumulate epilogue (ablation).  Bit-identical results for all. */
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
 
 /* Panel scheme of the blocked Cholesky (speed only; both are exact-Cholesky algebra).

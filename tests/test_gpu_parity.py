@@ -507,3 +507,23 @@ def test_default_panel_width_is_chosen_by_size():
     assert abs(lml_auto - lml_512) <= 1e-9 * abs(lml_512)
     assert rel_err(m_auto, m_512) < 1e-8
     assert r[0] < 1e-6 and r[1] < 1e-11
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_lookahead_depth_does_not_change_a_single_bit(scheme):
+    """look-ahead depth d: the panel stream updates the next panel left-looking from the last d panels, the
+    main stream the panels from k+d+1 on - every element still receives its updates in panel order"""
+    n = 5000
+    x, y = synthetic.make_cell_data(n, seed=1)
+    xq = synthetic.make_query(x, 100)
+    out = []
+    for la in (0, 1, 2, 3, 4, 1 | 8, 2 | 8):
+        e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+        e.set_options(nb_outer=512, lookahead=la)
+        e.set_panel_scheme(scheme)
+        lml, m, v = e.fit_predict(x, y, xq, min_var=-1.0)
+        out.append((lml, m, v, e.alpha()))
+        e.close()
+    for lml, m, v, a in out[1:]:
+        assert lml == out[0][0]
+        assert np.array_equal(m, out[0][1]) and np.array_equal(v, out[0][2]) and np.array_equal(a, out[0][3])
