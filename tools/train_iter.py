@@ -16,6 +16,8 @@ for n in [int(a) for a in sys.argv[1:]] or [1000, 4000, 16000]:
     x, y = synthetic.make_cell_data(n)
     xq = synthetic.make_query(x, 300)
     eng = ExactGPEngine(KERNEL_BATTGP, synthetic.HYP_BATTGP, device=0)
+    if os.environ.get("BGP_PANEL_SCHEME"):
+        eng.set_panel_scheme(int(os.environ["BGP_PANEL_SCHEME"]))
     eng.fit(x, y)
     eng.lml_grad()
     reps = 20 if n <= 4000 else 5
