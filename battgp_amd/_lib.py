@@ -21,6 +21,7 @@ SIGNATURES = {
     "bgp_version": (C.c_int, []),
     "bgp_create": (C.c_int, [C.POINTER(handle_p), C.c_int]),
     "bgp_destroy": (None, [handle_p]),
+    "bgp_trim": (C.c_int, [C.c_int]),
     "bgp_last_error": (C.c_char_p, [handle_p]),
     "bgp_set_kernel": (C.c_int, [handle_p, C.c_int, c_double_p, C.c_int]),
     "bgp_set_options": (C.c_int, [handle_p, C.c_int, C.c_int, C.c_double, C.c_int]),

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "bgp_internal.h"
 
 static thread_local std::string g_create_err;
@@ -21,6 +23,8 @@ int bgp_fail(bgp_handle* h, int code, const char* fmt, ...) {
   return code;
 }
 
+int pool_trim(int device);  // frees the idle handles of a device (all devices if < 0); returns how many
+
 namespace {
 
 inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
@@ -29,6 +33,11 @@ int dev_alloc(bgp_handle* h, double** p, int64_t n_doubles) {
   *p = nullptr;
   if (n_doubles <= 0) return 0;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)n_doubles * sizeof(double));
+  if (e != hipSuccess && pool_trim(h->device) > 0) {  // idle pooled handles may be holding the memory
+    (void)hipGetLastError();
+    (void)hipSetDevice(h->device);
+    e = hipMalloc(reinterpret_cast<void**>(p), (size_t)n_doubles * sizeof(double));
+  }
   if (e != hipSuccess) {
     *p = nullptr;
     (void)hipGetLastError();
@@ -457,6 +466,7 @@ void free_problem(bgp_handle* h) {
   h->N = h->Npad = h->lda = 0;
   h->D = 0;
   h->fitted = false;
+  h->has_data = false;
 }
 
 // Layout of the factor: full square when it fits (one launch per trailing update), column slabs
@@ -477,6 +487,10 @@ int choose_slab_width(bgp_handle* h, int64_t Npad, int64_t lda, int64_t* W_out) 
   BGP_HIP(h, hipMemGetInfo(&free_b, &total_b));
   // workspaces (two solved-panel buffers of the panel scheme), query buffers, runtime
   const double margin = 0.6e9 + (h->panel_mode == 1 ? ((h->lookahead & 7) + 1.0) * (double)lda * (double)NB * 8.0 : 0.0);
+  if ((double)lda * (double)Npad * 8.0 + margin > (double)free_b && pool_trim(h->device) > 0) {
+    (void)hipSetDevice(h->device);
+    BGP_HIP(h, hipMemGetInfo(&free_b, &total_b));  // idle pooled handles were holding memory
+  }
   if ((double)lda * (double)Npad * 8.0 + margin <= (double)free_b) {
     *W_out = BGP_W_FULL;
     return 0;
@@ -738,6 +752,99 @@ int check_handle(bgp_handle* h) {
 
 }  // namespace
 
+// ---- handle pool -----------------------------------------------------------------------------------
+// The reference builds one model object per cell and deletes it after the prediction
+// (src/batt_models/battgp_full.py:41-60,102-120): bgp_create + first fit + bgp_destroy are paid per cell -
+// measured 8.5 ms + 8.5 ms for streams / events / pinned buffers and, at N = 40 000, +147 ms for the
+// hipMalloc and first touch of the 13 GB factor, against 339 ms of work.  bgp_destroy therefore parks the
+// handle WITH its buffers (at most BGP_POOL = 2 per device; BGP_POOL=0 disables), bgp_create revives one
+// for the same device, and a same-sized problem finds its buffers in place.  Parked memory is given back
+// when an allocation fails or the automatic layout needs it, and by bgp_trim().
+namespace {
+struct HandlePool {
+  std::mutex mu;
+  std::vector<bgp_handle*> idle;
+  int max_per_device = 2;
+  bool init = false;
+};
+HandlePool& pool() {
+  static HandlePool p;
+  return p;
+}
+void pool_init_locked(HandlePool& p) {
+  if (p.init) return;
+  if (const char* e = getenv("BGP_POOL")) p.max_per_device = atoi(e);
+  p.init = true;
+}
+
+void destroy_now(bgp_handle* h) {
+  (void)hipSetDevice(h->device);
+  if (h->s_main) (void)hipStreamSynchronize(h->s_main);
+  free_problem(h);
+  dev_free(h, &h->dXq, h->Xq_cap);
+  free_panel_ws(h);
+  dev_free(h, &h->dpart, h->part_cap);
+  dev_free(h, &h->dout, h->out_cap);
+  if (h->dscal) (void)hipFree(h->dscal);
+  if (h->dinfo) (void)hipFree(h->dinfo);
+  if (h->hscal) (void)hipHostFree(h->hscal);
+  if (h->hinfo) (void)hipHostFree(h->hinfo);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
+  if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+  if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+  if (h->ev_c) (void)hipEventDestroy(h->ev_c);
+  if (h->ev_d) (void)hipEventDestroy(h->ev_d);
+  if (h->s_main) (void)hipStreamDestroy(h->s_main);
+  if (h->s_aux) (void)hipStreamDestroy(h->s_aux);
+  if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
+  delete h;
+}
+
+// a revived handle must behave like a new one: default options, no kernel, no fit - only the
+// resources (streams, events, pinned and device buffers of the last problem) survive
+void reset_logical(bgp_handle* h) {
+  const bgp_handle fresh;
+  h->kernel_set = false;
+  h->kernel_id = 0;
+  h->nhyp = 0;
+  h->nb_outer = fresh.nb_outer;
+  h->nb_auto = fresh.nb_auto;
+  h->max_tries = fresh.max_tries;
+  h->jitter0 = fresh.jitter0;
+  h->lookahead = fresh.lookahead;
+  h->panel_mode = fresh.panel_mode;
+  h->slab_req = fresh.slab_req;
+  h->fitted = false;
+  h->has_data = false;
+  h->alpha_ready = false;
+  h->jitter_used = 0.0;
+  h->lml = 0.0;
+  for (double& t : h->times) t = 0.0;
+  h->err.clear();
+  if (h->dA && h->slabW < h->Npad) free_problem(h);  // a slab layout is a per-problem decision: decide afresh
+}
+}  // namespace
+
+int pool_trim(int device) {
+  std::vector<bgp_handle*> victims;
+  {
+    HandlePool& p = pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    for (size_t i = 0; i < p.idle.size();) {
+      if (device < 0 || p.idle[i]->device == device) {
+        victims.push_back(p.idle[i]);
+        p.idle.erase(p.idle.begin() + (long)i);
+      } else {
+        ++i;
+      }
+    }
+  }
+  for (bgp_handle* v : victims) destroy_now(v);
+  return (int)victims.size();
+}
+
+
 extern "C" {
 
 int bgp_version(void) { return 100; }
@@ -752,6 +859,24 @@ int bgp_create(bgp_handle** out, int device) {
     return bgp_fail(nullptr, -2, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
   }
   if (device < 0 || device >= ndev) return bgp_fail(nullptr, -1, "device %d out of range (0..%d)", device, ndev - 1);
+  {
+    HandlePool& p = pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    for (size_t i = p.idle.size(); i-- > 0;) {
+      if (p.idle[i]->device == device) {
+        bgp_handle* r = p.idle[i];
+        p.idle.erase(p.idle.begin() + (long)i);
+        hipError_t e2 = hipSetDevice(device);
+        if (e2 != hipSuccess) {
+          p.idle.push_back(r);
+          return bgp_fail(nullptr, -2, "hipSetDevice(%d): %s", device, hipGetErrorString(e2));
+        }
+        reset_logical(r);
+        *out = r;
+        return 0;
+      }
+    }
+  }
   bgp_handle* h = new bgp_handle();
   h->device = device;
 #define CREATE_HIP(call)                                                                 \
@@ -759,7 +884,7 @@ int bgp_create(bgp_handle** out, int device) {
     hipError_t e2 = (call);                                                              \
     if (e2 != hipSuccess) {                                                              \
       bgp_fail(nullptr, -2, "%s failed: %s", #call, hipGetErrorString(e2));              \
-      bgp_destroy(h);                                                                    \
+      destroy_now(h);                                                                    \
       return -2;                                                                         \
     }                                                                                    \
   } while (0)
@@ -784,29 +909,29 @@ int bgp_create(bgp_handle** out, int device) {
   return 0;
 }
 
+int bgp_trim(int device) {
+  pool_trim(device);
+  return 0;
+}
+
 void bgp_destroy(bgp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->s_main) (void)hipStreamSynchronize(h->s_main);
-  free_problem(h);
-  dev_free(h, &h->dXq, h->Xq_cap);
-  free_panel_ws(h);
-  dev_free(h, &h->dpart, h->part_cap);
-  dev_free(h, &h->dout, h->out_cap);
-  if (h->dscal) (void)hipFree(h->dscal);
-  if (h->dinfo) (void)hipFree(h->dinfo);
-  if (h->hscal) (void)hipHostFree(h->hscal);
-  if (h->hinfo) (void)hipHostFree(h->hinfo);
-  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
-  if (h->ev_a) (void)hipEventDestroy(h->ev_a);
-  if (h->ev_b) (void)hipEventDestroy(h->ev_b);
-  if (h->ev_c) (void)hipEventDestroy(h->ev_c);
-  if (h->ev_d) (void)hipEventDestroy(h->ev_d);
-  if (h->s_main) (void)hipStreamDestroy(h->s_main);
-  if (h->s_aux) (void)hipStreamDestroy(h->s_aux);
-  if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
-  delete h;
+  if (h->s_aux) (void)hipStreamSynchronize(h->s_aux);
+  if (h->s_copy) (void)hipStreamSynchronize(h->s_copy);
+  {
+    HandlePool& p = pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    pool_init_locked(p);
+    int same = 0;
+    for (bgp_handle* q : p.idle) same += q->device == h->device;
+    if (h->s_main && same < p.max_per_device) {
+      p.idle.push_back(h);
+      return;
+    }
+  }
+  destroy_now(h);
 }
 
 const char* bgp_last_error(const bgp_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -885,6 +1010,7 @@ static int fit_common(bgp_handle* h, const double* X, const double* y, int64_t N
     BGP_HIP(h, hipMemcpyAsync(h->dy, y, (size_t)N * sizeof(double), kind, h->s_main));
     if ((rc = t.stop())) return rc;
   }
+  h->has_data = true;
   return fit_resident(h, lml_out, jitter_out);
 }
 
@@ -901,7 +1027,7 @@ int bgp_fit_dev(bgp_handle* h, const double* X_dev, const double* y_dev, int64_t
 int bgp_refit(bgp_handle* h, const double* hyp, int nhyp, double* lml_out, double* jitter_out) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (!h->dA || h->N < 1) return bgp_fail(h, -1, "bgp_refit: no resident problem (call bgp_fit first)");
+  if (!h->dA || h->N < 1 || !h->has_data) return bgp_fail(h, -1, "bgp_refit: no resident problem (call bgp_fit first)");
   if ((rc = bgp_set_kernel(h, h->kernel_id, hyp, nhyp))) return rc;
   return fit_resident(h, lml_out, jitter_out);
 }
@@ -926,6 +1052,7 @@ static int fit_predict_common(bgp_handle* h, const double* X, const double* y, i
     BGP_HIP(h, hipMemcpyAsync(h->dXq, Xq, (size_t)M * D * sizeof(double), kin, h->s_main));
     if ((rc = t.stop())) return rc;
   }
+  h->has_data = true;
   if ((rc = fit_resident(h, lml_out, jitter_out, M))) return rc;
   if ((rc = ride_posterior(h, M, var != nullptr, min_var))) return rc;
   {

@@ -81,6 +81,7 @@ struct bgp_handle {
   int64_t aug_used = BGP_AUG;  // rows of it that took part in the last factorisation
   int D = 0;
   bool fitted = false;
+  bool has_data = false;     // X, y were uploaded through THIS life of the handle (a revived pooled handle starts without)
   bool alpha_ready = false;
   double jitter_used = 0.0, lml = 0.0;
   // device buffers

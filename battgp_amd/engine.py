@@ -48,6 +48,11 @@ def as_device_index(device) -> int:
     return 0
 
 
+def trim_pool(device: int = -1) -> None:
+    """Release the HBM of parked (destroyed) engine handles - ``torch.cuda.empty_cache()`` for this engine."""
+    _lib.load().bgp_trim(int(device))
+
+
 class ExactGPEngine:
     def __init__(self, kernel_id: int, hyp, device=0):
         self._lib = _lib.load()

@@ -69,11 +69,18 @@ enum {
 int bgp_version(void);
 
 /* Create / destroy an engine bound to HIP device `device`.  The handle owns every device
- * buffer (K/L in place, X, y, alpha, workspaces); bgp_destroy frees them - this is what
+ * buffer (K/L in place, X, y, alpha, workspaces).  bgp_destroy is what
  * `del cellmodel.model; gc.collect(); torch.cuda.empty_cache()` does in the reference
- * (src/batt_models/battgp_full.py:102-120). */
+ * (src/batt_models/battgp_full.py:102-120) - with the allocator behaviour of torch: the reference
+ * builds one model per cell and deletes it after the prediction (battgp_full.py:41-60), so a destroyed
+ * handle is PARKED with its streams, events and buffers (at most BGP_POOL = 2 per device, environment
+ * variable; 0 = free at once) and the next bgp_create on that device revives it; a problem of the same
+ * size then finds its buffers in place (measured per cell: -17 ms, and -147 ms of hipMalloc + first touch
+ * at N = 40 000).  Parked memory is released when an allocation fails, when the automatic layout needs
+ * it, and by bgp_trim(device) (device < 0: all devices) - the counterpart of torch.cuda.empty_cache(). */
 int bgp_create(bgp_handle** out, int device);
 void bgp_destroy(bgp_handle* h);
+int bgp_trim(int device);
 
 /* Text of the last error on this handle ("" if none).  With h == NULL: last create error. */
 const char* bgp_last_error(const bgp_handle* h);

@@ -252,3 +252,42 @@ def test_system_driver_add_time_steps_large_m():
     # exactly as in the reference (battgp_full.py:86-96,112)
     assert res.df["t"].nunique() == 300 + 400 - 1 and np.all(np.diff(res.df["t"]) >= 0)
     assert np.isfinite(res.df.to_numpy()).all()
+
+
+def test_handle_pool_revives_handles_like_new_ones():
+    """bgp_destroy parks the handle (streams, events, buffers), bgp_create revives it: it must behave like a
+    fresh handle - default options, no kernel state, no stale data - and a same-sized problem reuses the buffers"""
+    from battgp_amd.engine import EngineError, ExactGPEngine, trim_pool
+
+    trim_pool()
+    x, y = synthetic.make_cell_data(3000, seed=1)
+    xq = synthetic.make_query(x, 50)
+    a = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    a.set_options(nb_outer=256, lookahead=0)
+    a.set_layout(512)
+    lml_a, m_a, v_a = a.fit_predict(x, y, xq)
+    a.close()
+    b = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)  # revived
+    with pytest.raises(EngineError):
+        b.refit(synthetic.HYP_BATTGP)  # no data in this life of the handle
+    with pytest.raises(EngineError):
+        b.predict(xq)
+    lml_b, m_b, v_b = b.fit_predict(x, y, xq)
+    assert b.layout()[0] == 0  # default (automatic) layout again, not the forced slabs of the previous owner
+    assert abs(lml_b - lml_a) <= 1e-9 * abs(lml_a) and np.allclose(m_b, m_a, rtol=1e-8, atol=0)
+    bytes_b = b.device_bytes()
+    b.close()
+    c = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    x2, y2 = synthetic.make_cell_data(3000, seed=2)
+    lml_c, m_c, _ = c.fit_predict(x2, y2, xq)
+    assert c.device_bytes() == bytes_b  # same size: buffers found in place
+    d = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)  # a second live handle is independent
+    lml_d, m_d, _ = d.fit_predict(x2, y2, xq)
+    assert lml_d == lml_c and np.array_equal(m_d, m_c)
+    c.close()
+    d.close()
+    trim_pool()
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    lml_e, m_e, _ = e.fit_predict(x2, y2, xq)
+    e.close()
+    assert lml_e == lml_c and np.array_equal(m_e, m_c)
