@@ -109,6 +109,15 @@ class BatteryCellGP_Full:
     def cellnr(self) -> int:
         return self._cellnr
 
+    def __delattr__(self, name):
+        # ``del cellmodel.model`` (src/batt_models/battgp_full.py:103,118) must release the engine handle and
+        # its HBM at once, without waiting for the garbage collector
+        if name == "model":
+            mdl = self.__dict__.get("model")
+            if mdl is not None:
+                mdl.close()
+        super().__delattr__(name)
+
     @staticmethod
     def get_default_parameters() -> dict[str, Any]:
         return {
