@@ -282,7 +282,9 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   // the matrix on a side stream.  24 launches over ~N/128 workgroups each -> 24 launches over <= 32
   // workgroups + one MFMA-bound launch: the chain no longer queues for CU slots behind the trailing
   // update, and the tall part runs at k = nbk instead of k = 64.
-  const bool dmode = h->panel_mode == 1 && nrows > NB;
+  // measured (bench.py --panel-scheme): N = 8000 10.1 vs 10.9 ms, 16384 38.5 vs 39.2, 24576 96.9 vs 96.4, 32768 209 vs 200
+  const int scheme = h->panel_mode >= 0 ? h->panel_mode : (n >= 24576 ? 1 : 0);
+  const bool dmode = scheme == 1 && nrows > NB;
   const int nbuf = depth + 1;  // solved-panel buffers alive at once: the sources of the next panel + the one being written
   if (dmode && (rc = ensure_panel_ws(h, nrows, NB, nbuf))) return rc;
   hipStream_t sc = h->s_copy;
@@ -486,7 +488,7 @@ int choose_slab_width(bgp_handle* h, int64_t Npad, int64_t lda, int64_t* W_out) 
   size_t free_b = 0, total_b = 0;
   BGP_HIP(h, hipMemGetInfo(&free_b, &total_b));
   // workspaces (two solved-panel buffers of the panel scheme), query buffers, runtime
-  const double margin = 0.6e9 + (h->panel_mode == 1 ? ((h->lookahead & 7) + 1.0) * (double)lda * (double)NB * 8.0 : 0.0);
+  const double margin = 0.6e9 + (h->panel_mode != 0 ? ((h->lookahead & 7) + 1.0) * (double)lda * (double)NB * 8.0 : 0.0);
   if ((double)lda * (double)Npad * 8.0 + margin > (double)free_b && pool_trim(h->device) > 0) {
     (void)hipSetDevice(h->device);
     BGP_HIP(h, hipMemGetInfo(&free_b, &total_b));  // idle pooled handles were holding memory
@@ -968,7 +970,7 @@ int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, 
 
 int bgp_set_panel_scheme(bgp_handle* h, int scheme) {
   if (!h) return -1;
-  if (scheme != 0 && scheme != 1) return bgp_fail(h, -1, "bgp_set_panel_scheme: scheme must be 0 or 1");
+  if (scheme < -1 || scheme > 1) return bgp_fail(h, -1, "bgp_set_panel_scheme: scheme must be -1 (automatic), 0 or 1");
   h->panel_mode = scheme;
   return 0;
 }

@@ -99,8 +99,9 @@ class ExactGPEngine:
     def set_options(self, nb_outer=-1, max_tries=-1, jitter0=-1.0, lookahead=-1) -> None:
         self._check(self._lib.bgp_set_options(self._h, nb_outer, max_tries, jitter0, lookahead), "bgp_set_options")
 
-    def set_panel_scheme(self, scheme: int = 1) -> None:
-        """1 (default): critical chain on the diagonal block + one deep TRSM-by-inverse GEMM; 0: 64-wide chain over all rows."""
+    def set_panel_scheme(self, scheme: int = -1) -> None:
+        """1: critical chain on the diagonal block + one deep TRSM-by-inverse GEMM; 0: 64-wide chain over all rows;
+        -1 (default): by size."""
         self._check(self._lib.bgp_set_panel_scheme(self._h, int(scheme)), "bgp_set_panel_scheme")
 
     def set_layout(self, slab_width: int = 0) -> None:

@@ -104,10 +104,11 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
 
 /* Panel scheme of the blocked Cholesky (speed only; both are exact-Cholesky algebra).
- *   1 (default)  the 64-wide critical chain runs on the nb_outer x nb_outer diagonal block only (with an
- *                identity block riding along that yields L_kk^-1); the rows below are solved by ONE
- *                deep MFMA GEMM with that inverse
- *   0            the 64-wide chain {tile Cholesky, TRSM by tile inverse, rank-64 update} over all rows */
+ *   1   the 64-wide critical chain runs on the nb_outer x nb_outer diagonal block only (with an identity
+ *       block riding along that yields L_kk^-1); the rows below are solved by ONE deep MFMA GEMM with that
+ *       inverse
+ *   0   the 64-wide chain {tile Cholesky, TRSM by tile inverse, rank-64 update} over all rows
+ *  -1   (default) automatic: 0 below N = 24 576, 1 from there on (measured crossover) */
 int bgp_set_panel_scheme(bgp_handle* h, int scheme);
 
 /* HBM layout of the in-place covariance / Cholesky factor ("N_max per GPU", BASELINE.json metric).
