@@ -158,7 +158,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=40000, help="training points per cell (configs[1]: 40 000)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=40000,
+                    help="training points per cell (configs[1]: 40 000); use --size under torch.distributed.run, whose argparse rejects --n as an ambiguous prefix of its own options")
     ap.add_argument("--m", type=int, default=300, help="query points (battgp_full.py:98)")
     ap.add_argument("--kernel", default="battgp", choices=["battgp", "matern32"])
     ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
@@ -167,6 +168,10 @@ def main() -> None:
     ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--separate", action="store_true", help="bgp_fit then bgp_predict (separate triangular-solve pass) instead of the fused call")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1: nccl (= RCCL, the driver's runs); gloo with --share-gpu rehearses "
+                         "the multi-rank path on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (rehearsal of the N > 1 path on one GPU)")
     ap.add_argument("--target-n", type=int, default=131072,
                     help="also report the kernels' roofline fractions at the north-star size (1 GPU only; 0 = skip)")
     args = ap.parse_args()
@@ -183,8 +188,11 @@ def main() -> None:
         raise SystemExit(
             f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
         )
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = parallel.init("nccl", device=torch.device("cuda", local_rank))  # RCCL; None for 1 process
+    dist = parallel.init(args.backend, device=torch.device("cuda", local_rank))  # nccl = RCCL; None for 1 process
+    red_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     kernel_id, hyp = (
         (KERNEL_BATTGP, synthetic.HYP_BATTGP) if args.kernel == "battgp" else (KERNEL_MATERN32, synthetic.HYP_MATERN32)
@@ -230,7 +238,7 @@ def main() -> None:
         phases.append(eng.phase_times())
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(dist, elapsed, device=dev)
+    elapsed = parallel.max_over_ranks(dist, elapsed, device=red_dev)
 
     # The la(k) and rest(k) launches of a panel overlap each other in the default schedule (fastest wall
     # clock), which stretches both event-timed durations.  One extra, untimed step with la(k) ordered before
