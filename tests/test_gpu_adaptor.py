@@ -291,3 +291,39 @@ def test_handle_pool_revives_handles_like_new_ones():
     lml_e, m_e, _ = e.fit_predict(x2, y2, xq)
     e.close()
     assert lml_e == lml_c and np.array_equal(m_e, m_c)
+
+
+def test_handle_pool_is_thread_safe():
+    """the reference trains cells from a thread pool (src/batt_models/battgp.py:191-216): handles are created and
+    destroyed concurrently; parked handles must never be shared and results must not depend on the interleaving"""
+    from battgp_amd.engine import ExactGPEngine, trim_pool
+
+    trim_pool()
+    cases = []
+    for i, n in enumerate((300, 700, 700, 1100)):
+        x, y = synthetic.make_cell_data(n, seed=50 + i)
+        xq = synthetic.make_query(x, 40)
+        e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+        lml, m, v = e.fit_predict(x, y, xq)
+        e.close()
+        cases.append((x, y, xq, lml, m, v))
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(12):
+                x, y, xq, lml, m, v = cases[(tid + it) % len(cases)]
+                e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+                got = e.fit_predict(x, y, xq)
+                e.close()
+                assert got[0] == lml and np.array_equal(got[1], m) and np.array_equal(got[2], v)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    trim_pool()
