@@ -767,6 +767,7 @@ struct HandlePool {
   std::mutex mu;
   std::vector<bgp_handle*> idle;
   int max_per_device = 2;
+  int64_t max_bytes = (int64_t)40 << 30;  // a parked handle keeps its buffers only up to this size (BGP_POOL_BYTES)
   bool init = false;
 };
 HandlePool& pool() {
@@ -776,6 +777,7 @@ HandlePool& pool() {
 void pool_init_locked(HandlePool& p) {
   if (p.init) return;
   if (const char* e = getenv("BGP_POOL")) p.max_per_device = atoi(e);
+  if (const char* e = getenv("BGP_POOL_BYTES")) p.max_bytes = atoll(e);
   p.init = true;
 }
 
@@ -929,6 +931,12 @@ void bgp_destroy(bgp_handle* h) {
     int same = 0;
     for (bgp_handle* q : p.idle) same += q->device == h->device;
     if (h->s_main && same < p.max_per_device) {
+      // big problems give their HBM back at once (N = 131 072 would park 138 GB that torch or the next,
+      // differently sized model may need); the shell - streams, events, pinned buffers - is still worth keeping
+      if (h->bytes > p.max_bytes) {
+        free_problem(h);
+        free_panel_ws(h);
+      }
       p.idle.push_back(h);
       return;
     }
