@@ -63,6 +63,10 @@ SIGNATURES = {
     ),
     "bgp_aug_rows_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]),
     "bgp_factor_panel_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, c_int_p]),
+    "bgp_factor_pack_panel_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, c_int_p],
+    ),
     "bgp_solve_panel_dev": (
         C.c_int,
         [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p],
@@ -71,6 +75,7 @@ SIGNATURES = {
         C.c_int,
         [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int],
     ),
+    "bgp_update_panels_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     "bgp_diag_logsum_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
     "bgp_rowdot_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "bgp_var_finish_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double, C.c_void_p]),

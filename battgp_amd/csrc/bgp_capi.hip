@@ -1308,6 +1308,35 @@ int bgp_factor_panel_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t n
   return 0;
 }
 
+int bgp_factor_pack_panel_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t nrows, int nbk, double* inv_dev,
+                              double* pack_dev, int* info_out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const int64_t NB = h->nb_outer;
+  if (!panel_dev || !inv_dev || !pack_dev || nbk < 64 || (nbk % 64) != 0 || nbk > NB || nrows < nbk || (nrows & 1) ||
+      (ld & 1))
+    return bgp_fail(h, -1, "bgp_factor_pack_panel_dev: bad arguments (nrows=%lld nbk=%d ld=%lld nb_outer=%lld)",
+                    (long long)nrows, nbk, (long long)ld, (long long)NB);
+  if ((rc = ensure_panel_ws(h, 0, NB, 0))) return rc;  // diagonal-block workspace + L_kk^-1 only
+  hipStream_t st = h->s_main;
+  const int64_t ldd = 2 * NB, below = nrows - nbk;
+  BGP_HIP(h, hipMemsetAsync(h->dinfo, 0, sizeof(int), st));
+  if ((rc = launch_diag_in(h, st, panel_dev, ld, h->dD, ldd, nbk))) return rc;
+  if ((rc = factor_panel(h, st, h->dD, 2 * (int64_t)nbk, ldd, inv_dev, h->dinfo, 0, nbk))) return rc;
+  if ((rc = launch_diag_out(h, st, h->dD, ldd, panel_dev, ld, h->dLinv, NB, nbk))) return rc;
+  // packed panel: its diagonal block, then the rows below solved against the explicit inverse
+  if ((rc = launch_copy_panel(h, st, panel_dev, ld, pack_dev, nrows, nbk, nbk))) return rc;
+  if (below > 0) {
+    rc = launch_gemm_nt(h, st, 1, 64, pack_dev + nbk, nrows, panel_dev + nbk, ld, h->dLinv, NB, below, nbk, nbk, 0, h->dinfo, 1);
+    if (rc) return rc;
+    if ((rc = launch_copy_panel(h, st, pack_dev + nbk, nrows, panel_dev + nbk, ld, below, nbk))) return rc;
+  }
+  int info = 0;
+  if ((rc = check_info(h, st, nullptr, h->dinfo, &info))) return rc;
+  if (info_out) *info_out = info;
+  return 0;
+}
+
 int bgp_solve_panel_dev(bgp_handle* h, double* E_dev, int64_t lde, int64_t me, const double* Lkk_dev, int64_t ld,
                         int nbk, const double* inv_dev) {
   int rc = check_handle(h);
@@ -1321,6 +1350,32 @@ int bgp_gemm_nt_sub_async_dev(bgp_handle* h, double* C_dev, int64_t ldc, const d
   int rc = check_handle(h);
   if (rc) return rc;
   return launch_gemm_nt(h, h->s_main, 0, 128, C_dev, ldc, A_dev, lda, B_dev, ldb, m, n, k, lower);
+}
+
+int bgp_update_panels_dev(bgp_handle* h, double* store_dev, int64_t ld, const int64_t* desc, int count,
+                          const double* P_dev, int64_t ldp, int k) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!store_dev || !desc || !P_dev || count < 0 || k < 1)
+    return bgp_fail(h, -1, "bgp_update_panels_dev: bad arguments (count=%d k=%d)", count, k);
+  if (count == 0) return 0;
+  hipEvent_t ev;
+  // the second stream joins after everything already queued on the first (the panel is complete) ...
+  if ((rc = sync_event(h, 0, &ev))) return rc;
+  BGP_HIP(h, hipEventRecord(ev, h->s_main));
+  BGP_HIP(h, hipStreamWaitEvent(h->s_aux, ev, 0));
+  const int tmode = k >= 256 ? 2 : 0;
+  for (int i = 0; i < count; ++i) {
+    const int64_t* d = desc + 4 * (int64_t)i;
+    hipStream_t st = (i & 1) ? h->s_aux : h->s_main;
+    const double* P = P_dev + d[3];
+    if ((rc = launch_gemm_nt(h, st, tmode, 128, store_dev + d[0], ld, P, ldp, P, ldp, d[1], d[2], k, 1))) return rc;
+  }
+  // ... and the first waits for it, so that later work queued on the first stream sees every update
+  if ((rc = sync_event(h, 1, &ev))) return rc;
+  BGP_HIP(h, hipEventRecord(ev, h->s_aux));
+  BGP_HIP(h, hipStreamWaitEvent(h->s_main, ev, 0));
+  return 0;
 }
 
 int bgp_diag_logsum_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t n, double* out_host) {

@@ -135,6 +135,17 @@ class DeviceBackend:
         )
         return int(info.value)
 
+    def factor_pack(self, store, ld, lcol0, col0, rows, nbk, inv, pbuf):
+        """factor the panel and leave its packed copy in pbuf (one C call; see bgp_factor_pack_panel_dev)"""
+        info = C.c_int(0)
+        self._chk(
+            self.lib.bgp_factor_pack_panel_dev(
+                self.h, self._p(store, lcol0 * ld + col0), ld, rows, nbk, self._p(inv), self._p(pbuf), C.byref(info)
+            ),
+            "bgp_factor_pack_panel_dev",
+        )
+        return int(info.value)
+
     def pack_panel(self, store, ld, lcol0, col0, rows, nbk, pbuf):
         """pbuf[r + c*rows] = store[(col0 + r) + (lcol0 + c)*ld]"""
         t = self.torch
@@ -148,6 +159,18 @@ class DeviceBackend:
                 self.h, self._p(store, lcol0 * ld + colj), ld, self._p(pbuf, off), ldp, self._p(pbuf, off), ldp, rows_j, nbj, nbk, 1
             ),
             "bgp_gemm_nt_sub_async_dev",
+        )
+
+    def update_panels(self, store, ld, items, pbuf, ldp, nbk):
+        """items: (lcol0, colj, rows_j, nbj, p_off) per local panel - all updates of one step in one C call"""
+        if not items:
+            return
+        desc = np.ascontiguousarray([[lc * ld + cj, rows_j, nbj, off] for lc, cj, rows_j, nbj, off in items], dtype=np.int64)
+        self._chk(
+            self.lib.bgp_update_panels_dev(
+                self.h, self._p(store), ld, desc.ctypes.data_as(C.POINTER(C.c_int64)), len(items), self._p(pbuf), ldp, nbk
+            ),
+            "bgp_update_panels_dev",
         )
 
     def diag_logsum(self, store, ld, lcol0, col0, nbk) -> float:
@@ -289,9 +312,7 @@ class ShardedExactGP:
 
         def factor_and_pack(k, buf):
             c0, nbk, rows = lay.col0(k), lay.width(k), lay.rows_from(k)
-            info = be.factor_panel(self.store, ld, self.lcol0[k], c0, rows, nbk, self.inv[k])
-            if info == 0:
-                be.pack_panel(self.store, ld, self.lcol0[k], c0, rows, nbk, buf)
+            info = be.factor_pack(self.store, ld, self.lcol0[k], c0, rows, nbk, self.inv[k], buf)
             buf[nbk * rows] = float(info + c0 if info else 0)
             be.after_comm()
 
@@ -323,9 +344,9 @@ class ShardedExactGP:
                 factor_and_pack(k + 1, nxt)
                 todo.remove(k + 1)
             work = start_bcast(k + 1, nxt)
-            for j in todo:
-                cj, nbj = lay.col0(j), lay.width(j)
-                be.update_panel(self.store, ld, self.lcol0[j], cj, lay.rows_from(j), nbj, cur, rows, cj - c0, nbk)
+            be.update_panels(
+                self.store, ld, [(self.lcol0[j], lay.col0(j), lay.rows_from(j), lay.width(j), lay.col0(j) - c0) for j in todo], cur, rows, nbk
+            )
             be.sync()
         return 0
 

@@ -239,6 +239,13 @@ int bgp_aug_rows_dev(bgp_handle* h, const double* y_dev, int64_t N, int64_t col0
 int bgp_factor_panel_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t nrows, int nbk,
                          double* inv_dev, int* info_out);
 
+/* bgp_factor_panel_dev with the single-GPU engine's panel scheme 1 and the packing for the broadcast fused in:
+ * the 64-wide chain runs on the nbk x nbk diagonal block only (riding identity -> L_kk^-1), the rows below
+ * are solved by ONE MFMA GEMM straight into the packed buffer pack_dev [nrows, nbk] (ld = nrows), and
+ * copied back into the panel.  nbk <= nb_outer. */
+int bgp_factor_pack_panel_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t nrows, int nbk, double* inv_dev,
+                              double* pack_dev, int* info_out);
+
 /* E_K <- E_K L_KK^-T for a row block E_K[me, nbk] against a factored panel's diagonal block. */
 int bgp_solve_panel_dev(bgp_handle* h, double* E_dev, int64_t lde, int64_t me, const double* Lkk_dev,
                         int64_t ld, int nbk, const double* inv_dev);
@@ -246,6 +253,15 @@ int bgp_solve_panel_dev(bgp_handle* h, double* E_dev, int64_t lde, int64_t me, c
 /* bgp_gemm_nt_sub_dev without the trailing synchronisation. */
 int bgp_gemm_nt_sub_async_dev(bgp_handle* h, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
                               const double* B_dev, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower);
+
+/* All rank-k updates of one step of the sharded factorisation in one call: for i < count
+ *   C_i[rows_i, ncols_i] -= P[p_off_i .. , 0..k) P[p_off_i .. p_off_i + ncols_i, 0..k)^T    (lower trapezoid)
+ * with C_i = store_dev + desc[4 i], rows_i = desc[4 i + 1], ncols_i = desc[4 i + 2], p_off_i = desc[4 i + 3]
+ * (desc on the host).  The launches alternate between the engine's two streams, so that the partial last
+ * round of workgroups of one panel's update overlaps the next panel's; deep updates (k >= 256) accumulate
+ * through L2 atomics like the single-GPU trailing update.  Asynchronous (bgp_sync). */
+int bgp_update_panels_dev(bgp_handle* h, double* store_dev, int64_t ld, const int64_t* desc, int count,
+                          const double* P_dev, int64_t ldp, int k);
 
 /* out_host[0] = sum_{i<n} log A[i + i*ld] (half log-determinant of a factored diagonal block). Synchronous. */
 int bgp_diag_logsum_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t n, double* out_host);

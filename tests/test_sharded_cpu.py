@@ -72,12 +72,22 @@ class NumpyBackend:
         p[nbk:] = np.linalg.solve(l11, p[nbk:].T).T
         return 0
 
+    def factor_pack(self, store, ld, lcol0, col0, rows, nbk, inv, pbuf):
+        info = self.factor_panel(store, ld, lcol0, col0, rows, nbk, inv)
+        if info == 0:
+            self.pack_panel(store, ld, lcol0, col0, rows, nbk, pbuf)
+        return info
+
     def pack_panel(self, store, ld, lcol0, col0, rows, nbk, pbuf):
         pbuf[: nbk * rows] = self._cm(store, lcol0 * ld + col0, rows, nbk, ld).T.reshape(-1)
 
     def update_panel(self, store, ld, lcol0, colj, rows_j, nbj, pbuf, ldp, off, nbk):
         pm = self._cm(pbuf, off, rows_j, nbk, ldp)
         self._cm(store, lcol0 * ld + colj, rows_j, nbj, ld)[:] -= pm @ pm[:nbj].T
+
+    def update_panels(self, store, ld, items, pbuf, ldp, nbk):
+        for lc, cj, rows_j, nbj, off in items:
+            self.update_panel(store, ld, lc, cj, rows_j, nbj, pbuf, ldp, off, nbk)
 
     def diag_logsum(self, store, ld, lcol0, col0, nbk):
         return float(np.sum(np.log(np.diag(self._cm(store, lcol0 * ld + col0, nbk, nbk, ld)))))
