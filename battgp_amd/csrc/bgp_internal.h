@@ -94,6 +94,9 @@ struct bgp_handle {
   double* dalpha = nullptr;  // [Npad]
   double* dB = nullptr;      // gradient workspace: U = L^-T (upper), [lda, Npad]; allocated on first bgp_lml_grad
   double* dS = nullptr;      // gradient workspace: S = -Sigma^-1 (lower), [lda, Npad]
+  double* dLinvAll = nullptr;  // inv(L_pp) of every outer panel [npanels][nbL * nbL]: later query blocks (predict after fit)
+  int64_t LinvAll_cap = 0;
+  int64_t LinvAll_nb = 0;      // panel width they were built for; 0 = not valid for the current factor
   // panel workspaces (panel_mode 1): diagonal block + riding identity, L_kk^-1, two solved-panel buffers
   double* dD = nullptr;      // [2 nbw, nbw]
   double* dLinv = nullptr;   // [nbw, nbw]
@@ -135,6 +138,8 @@ int launch_fill(bgp_handle* h, hipStream_t st, const FillParams& p, const double
 int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, int64_t ldc,
                    const double* A, int64_t lda, const double* B, int64_t ldb, int64_t m, int64_t n,
                    int64_t k, int lower, const int* abort_flag = nullptr, int btri = 0);
+int launch_trinv_panels(bgp_handle* h, hipStream_t st, const SlabView& L, const double* inv_tiles, double* Linv_all,
+                        int64_t n, int NB);
 int launch_diag_in(bgp_handle* h, hipStream_t st, const double* Akk, int64_t lda, double* D, int64_t ldd, int nbk);
 int launch_diag_out(bgp_handle* h, hipStream_t st, const double* D, int64_t ldd, double* Akk, int64_t lda,
                     double* Linv, int64_t ldl, int nbk);

@@ -403,6 +403,90 @@ __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(double* __restrict__
   }
 }
 
+// ---- explicit inverses of ALL diagonal panel blocks of a factor, in one launch ---------------------
+// Linv_all[p] (ld = NB) = inv(L_pp) for every outer panel p, from the factor's blocks and the stored 64 x 64
+// tile inverses by block forward substitution:  X_jj = inv_j,  X_ij = -inv_i sum_{q=j}^{i-1} L_iq X_qj.
+// One workgroup per (panel, block column j): the block columns are independent, so the whole launch is as
+// long as ONE chain of <= NB/64 - 1 steps.  With these inverses a later query block goes through the factor
+// with 3 launches per outer panel (solve by inverse, copy, deep update) instead of 2 per 64 columns.
+// Plain fp64 FMA on 64 x 64 blocks staged in LDS (4 x 4 outputs per thread): latency, not throughput,
+// is what matters here.
+__global__ __launch_bounds__(256) void trinv_panels_kernel(SlabView L, const double* __restrict__ inv_tiles,
+                                                           double* __restrict__ Linv_all, int64_t n, int NB) {
+  __shared__ double sA[64][65];  // [r][k]
+  __shared__ double sB[64][65];  // [k][c]
+  const int nblk_max = NB / 64;
+  const int p = (int)blockIdx.x / nblk_max, jb = (int)blockIdx.x % nblk_max;
+  const int64_t K0 = (int64_t)p * NB;
+  const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+  const int nblk = (int)(nbk / 64);
+  if (jb >= nblk) return;
+  double* X = Linv_all + (int64_t)p * NB * NB;
+  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+  const double* tiles = inv_tiles + (K0 / 64) * 4096;
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int r = idx & 63, c = idx >> 6;
+    X[(64 * jb + r) + (int64_t)(64 * jb + c) * NB] = tiles[(int64_t)jb * 4096 + idx];
+  }
+  for (int i = jb + 1; i < nblk; ++i) {
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int q = jb; q < i; ++q) {
+      __threadfence_block();
+      __syncthreads();  // previous products done with sA / sB; X blocks written by this workgroup visible
+      for (int idx = tid; idx < 4096; idx += 256) {
+        const int r = idx & 63, c = idx >> 6;
+        sA[r][c] = *L.at(K0 + 64 * i + r, K0 + 64 * q + c);        // L_iq (r, k = c)
+        sB[r][c] = X[(64 * q + r) + (int64_t)(64 * jb + c) * NB];  // X_qj (k = r, c)
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int k = 0; k < 64; ++k) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) av[a] = sA[4 * tr + a][k];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bv[b] = sB[k][4 * tc + b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(av[a], bv[b], acc[a][b]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sB[4 * tr + a][4 * tc + b] = acc[a][b];  // S as [k][c]
+    for (int idx = tid; idx < 4096; idx += 256) sA[idx & 63][idx >> 6] = tiles[(int64_t)i * 4096 + idx];  // inv_i (r, k)
+    __syncthreads();
+    double out[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) out[a][b] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < 64; ++k) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = sA[4 * tr + a][k];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = sB[k][4 * tc + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) out[a][b] = __builtin_fma(-av[a], bv[b], out[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) X[(64 * i + 4 * tr + a) + (int64_t)(64 * jb + 4 * tc + b) * NB] = out[a][b];
+  }
+}
+
 // out[0] = sum_i log A_ii, out[1] = sum_i z_i^2   (z strided by ldz).  One workgroup.
 __global__ __launch_bounds__(1024) void fit_scalars_kernel(SlabView A, const double* __restrict__ z, int64_t ldz,
                                                            int64_t n, double* __restrict__ out) {
@@ -720,6 +804,16 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv, int* info,
                       int col0, int /*nvalid*/) {
   hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_trinv_panels(bgp_handle* h, hipStream_t st, const SlabView& L, const double* inv_tiles, double* Linv_all,
+                        int64_t n, int NB) {
+  const int64_t npanels = (n + NB - 1) / NB;
+  BGP_HIP(h, hipMemsetAsync(Linv_all, 0, (size_t)npanels * NB * NB * sizeof(double), st));
+  hipLaunchKernelGGL(trinv_panels_kernel, dim3((unsigned)(npanels * (NB / 64))), dim3(256), 0, st, L, inv_tiles, Linv_all,
+                     n, NB);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }
