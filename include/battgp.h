@@ -74,8 +74,8 @@ int bgp_version(void);
  * (src/batt_models/battgp_full.py:102-120) - with the allocator behaviour of torch: the reference
  * builds one model per cell and deletes it after the prediction (battgp_full.py:41-60), so a destroyed
  * handle is PARKED with its streams, events and - up to BGP_POOL_BYTES = 40 GiB - buffers (at most
- * BGP_POOL = 2 per device, environment variables; BGP_POOL=0 = free at once) and the next bgp_create on that device revives it; a problem of the same
- * size then finds its buffers in place (measured per cell: -17 ms, and -147 ms of hipMalloc + first touch
+ * BGP_POOL = 2 per device, environment variables; BGP_POOL=0 = free at once) and the next bgp_create on
+ * that device revives it as a logically new handle; a problem of the same size then finds its buffers in place (measured per cell: -17 ms, and -147 ms of hipMalloc + first touch
  * at N = 40 000).  Parked memory is released when an allocation fails, when the automatic layout needs
  * it, and by bgp_trim(device) (device < 0: all devices) - the counterpart of torch.cuda.empty_cache(). */
 int bgp_create(bgp_handle** out, int device);
@@ -115,7 +115,8 @@ int bgp_set_panel_scheme(bgp_handle* h, int scheme);
  *   slab_width = -1  full square [lda, Npad] column-major: 8 N^2 bytes (N_max ~ 196 000 on 288 GB)
  *   slab_width >  0  column slabs of that width (multiple of nb_outer), each keeping only the rows
  *                    from its own diagonal block down: ~4 N (N + slab_width) bytes - N = 262 144
- *                    (BASELINE config 4's size) fits on ONE MI355X; results are bit-identical
+ *                    (BASELINE config 4's size) fits on ONE MI355X, N_max = 274 432 measured; results are
+ *                    bit-identical to the full square
  *   slab_width =  0  (default) full square when it fits in free HBM, else the widest slab that does
  * Changing the layout drops the resident problem.  bgp_get_layout reports the width in use by the
  * resident problem (0 = full square) and the bytes of the factor buffer.  No reference call site
