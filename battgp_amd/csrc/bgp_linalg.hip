@@ -775,7 +775,11 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
                     (long long)m, (long long)n, (long long)lda, (long long)ldb);
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
     return bgp_fail(h, -1, "gemm_nt: operands must be 16-byte aligned");
-  const int TM = 128;
+  // the 64-deep steps of the panel chain on a few thousand rows: 64 x 64 tiles put four times as many CUs
+  // on the (latency-bound) launch as long as everything still fits one round of workgroup slots
+  const bool t64 = k == 64 && (mode == 0 || mode == 1) && ((m + 63) / 64) * ((n + 63) / 64) <= 512;
+  const int TM = t64 ? 64 : 128;
+  if (t64) tn = 64;
   const int nti = (int)((m + TM - 1) / TM), ntj = (int)((n + tn - 1) / tn);
   // up to one super-tile round per XCD of tiles: direct mapping (bit 1 of `lower`), exact grid
   const bool small = (int64_t)nti * ntj <= 512;
@@ -783,7 +787,13 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
   const int64_t blocks = small ? (int64_t)nti * ntj : gemm_grid_blocks(nti, ntj, lower);
   if (blocks > 0x7fffffffLL) return bgp_fail(h, -1, "gemm_nt: grid too large");
   dim3 grid((unsigned)blocks), block(256);
-  if (tn == 128 && mode == 0)
+  if (t64 && mode == 0)
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
+                       (int)k, lower, nti, ntj, abort_flag, btri);
+  else if (t64 && mode == 1)
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
+                       (int)k, lower, nti, ntj, abort_flag, btri);
+  else if (tn == 128 && mode == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
                        (int)k, lower, nti, ntj, abort_flag, btri);
   else if (tn == 128 && mode == 2)
