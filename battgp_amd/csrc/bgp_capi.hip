@@ -282,8 +282,9 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   // the matrix on a side stream.  24 launches over ~N/128 workgroups each -> 24 launches over <= 32
   // workgroups + one MFMA-bound launch: the chain no longer queues for CU slots behind the trailing
   // update, and the tall part runs at k = nbk instead of k = 64.
-  // measured (bench.py --panel-scheme): N = 8000 10.1 vs 10.9 ms, 16384 38.5 vs 39.2, 24576 96.9 vs 96.4, 32768 209 vs 200
-  const int scheme = h->panel_mode >= 0 ? h->panel_mode : (n >= 24576 ? 1 : 0);
+  // measured (bench.py --panel-scheme, scheme 0 vs 1): N = 12288 20.9 vs 21.6 ms, 16384 37.5 vs 37.6, 24576 96.2 vs 94.6,
+  // 32768 208 vs 198
+  const int scheme = h->panel_mode >= 0 ? h->panel_mode : (n >= 16384 ? 1 : 0);
   const bool dmode = scheme == 1 && nrows > NB;
   const int nbuf = depth + 1;  // solved-panel buffers alive at once: the sources of the next panel + the one being written
   if (dmode && (rc = ensure_panel_ws(h, nrows, NB, nbuf))) return rc;

@@ -777,7 +777,7 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
     return bgp_fail(h, -1, "gemm_nt: operands must be 16-byte aligned");
   // the 64-deep steps of the panel chain on a few thousand rows: 64 x 64 tiles put four times as many CUs
   // on the (latency-bound) launch as long as everything still fits one round of workgroup slots
-  const bool t64 = k == 64 && (mode == 0 || mode == 1) && ((m + 63) / 64) * ((n + 63) / 64) <= 512;
+  const bool t64 = k == 64 && (mode == 0 || mode == 1) && ((m + 63) / 64) * ((n + 63) / 64) <= 1536;
   const int TM = t64 ? 64 : 128;
   if (t64) tn = 64;
   const int nti = (int)((m + TM - 1) / TM), ntj = (int)((n + tn - 1) / tn);

@@ -108,7 +108,7 @@ int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, 
  *       block riding along that yields L_kk^-1); the rows below are solved by ONE deep MFMA GEMM with that
  *       inverse
  *   0   the 64-wide chain {tile Cholesky, TRSM by tile inverse, rank-64 update} over all rows
- *  -1   (default) automatic: 0 below N = 24 576, 1 from there on (measured crossover) */
+ *  -1   (default) automatic: 0 below N = 16 384, 1 from there on (measured crossover) */
 int bgp_set_panel_scheme(bgp_handle* h, int scheme);
 
 /* HBM layout of the in-place covariance / Cholesky factor ("N_max per GPU", BASELINE.json metric).
