@@ -697,7 +697,7 @@ int ensure_query_small(bgp_handle* h, int64_t M) {
     if (rc) return rc;
     h->out_cap = 2 * M;
   }
-  return ensure_part(h, ((h->Npad + 511) / 512 + 1) * M);
+  return ensure_part(h, ((h->Npad + BGP_RD_COLS - 1) / BGP_RD_COLS + 1) * M);
 }
 
 // + the [Mpad, Npad] block of the separate triangular-solve pass
@@ -721,7 +721,7 @@ int ride_posterior(bgp_handle* h, int64_t M, bool want_var, double min_var) {
   if (rc) return rc;
   const SlabView V = h->view();
   const int64_t Npad = h->Npad;
-  // partial row sums per 512-column chunk, slab by slab (slab widths are multiples of the chunk)
+  // partial row sums per BGP_RD_COLS-column chunk, slab by slab (slab widths are multiples of the chunk)
   auto rowdot_all = [&](const double* vec, int* nch_out) -> int {
     int nch = 0;
     for (int64_t c0 = 0; c0 < Npad;) {
@@ -1440,7 +1440,7 @@ int bgp_rowdot_dev(bgp_handle* h, const double* E_dev, int64_t lde, int64_t M, i
                    double* out_dev) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if ((rc = ensure_part(h, ((n + 511) / 512 + 1) * M))) return rc;
+  if ((rc = ensure_part(h, ((n + BGP_RD_COLS - 1) / BGP_RD_COLS + 1) * M))) return rc;
   int nch = 0;
   if ((rc = launch_rowdot(h, h->s_main, E_dev, lde, M, n, vec_dev, h->dpart, &nch))) return rc;
   FillParams p;
@@ -1503,7 +1503,7 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   // alpha = L^-T z = U z comes for one pass over U (the panel-wise backward solve costs one latency-bound
   // single-workgroup kernel per outer panel: 0.3 of 1.8 ms at N = 1000)
   if (!h->alpha_ready) {
-    if ((rc = ensure_part(h, ((n + 511) / 512 + 1) * n))) return rc;
+    if ((rc = ensure_part(h, ((n + BGP_RD_COLS - 1) / BGP_RD_COLS + 1) * n))) return rc;
     int nch = 0;
     if ((rc = launch_rowdot(h, st, U, lda, n, n, h->dz, h->dpart, &nch))) return rc;
     FillParams p0;

@@ -10,6 +10,7 @@
 #include "../../include/battgp.h"
 
 #define BGP_IB 64  // inner (diagonal tile) block of the Cholesky; also the K-granule of the path
+#define BGP_RD_COLS 128  // columns per workgroup of the row-dot reductions (partial sums: ceil(n / 128) per row)
 #define BGP_MAX_WBUF 5  // solved-panel workspaces (look-ahead depth <= 4)
 #define BGP_AUG 64 // rows of the augmented block below the matrix (row 0 of it carries y^T)
 

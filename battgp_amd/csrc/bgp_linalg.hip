@@ -595,7 +595,7 @@ __global__ __launch_bounds__(512) void trsv_block_bwd_kernel(const double* __res
 
 // ---- row-wise reductions over the query block E[M, n] (column-major, rows contiguous) ---------
 // part[chunk][m] = sum_{i in chunk} E[m,i] * (vec ? vec[i] : E[m,i])
-constexpr int RD_COLS = 512;
+constexpr int RD_COLS = BGP_RD_COLS;  // 128: four times the workgroups of a 512-column chunk on a latency-bound pass
 __global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ E, int64_t lde, int64_t M,
                                                      int64_t n, const double* __restrict__ vec,
                                                      double* __restrict__ part) {
