@@ -44,7 +44,9 @@ fill_alg = 4.0 * n * (n + 1) + 8.0 * m * n
 classes = {}
 for name, frag in (("trailing_update_gemm_nt_128x128_mode2", "gemm_nt_kernel<128, 128, 2"),
                    ("panel_update_gemm_nt_128x128_mode0", "gemm_nt_kernel<128, 128, 0"),
-                   ("trsm_gemm_nt_128x64_mode1", "gemm_nt_kernel<128, 64, 1")):
+                   ("chain_update_gemm_nt_64x64_mode0", "gemm_nt_kernel<64, 64, 0"),
+                   ("chain_trsm_gemm_nt_64x64_mode1", "gemm_nt_kernel<64, 64, 1"),
+                   ("trsm_by_panel_inverse_gemm_nt_128x64_mode1", "gemm_nt_kernel<128, 64, 1")):
     calls, f = pick(fetch, frag, "FETCH_SIZE")
     _, w = pick(write, frag, "WRITE_SIZE")
     _, busy = pick(mfma, frag, "SQ_VALU_MFMA_BUSY_CYCLES")
