@@ -54,16 +54,15 @@ __device__ __forceinline__ double exp_nonpos(double x, const double* __restrict_
   return __builtin_ldexp(t * p, k >> 6);
 }
 
-// sqrt(q), q >= 0, to ~1 ulp: v_rsq_f64 seed + one coupled Newton step + residual correction
-// (8 VALU ops; the library sqrt costs ~2x and made the Matern fill VALU-bound)
+// sqrt(q), q >= 0, to ~1.5 ulp: v_rsq_f64 seed (2^-26) times q, then ONE residual correction with the seed's own
+// half-reciprocal, r += (q - r^2) y / 2: the error is ~1.5 (2^-26)^2.  5 VALU ops (+ the quarter-rate rsq); the
+// coupled Newton step that brings it to 0.5 ulp costs 3 more and 2.4 % of the Matern fill rate; the library
+// sqrt costs ~2x and made the fill VALU-bound.  Elementwise parity of the kernel matrix stays < 2e-13.
 __device__ __forceinline__ double sqrt_nonneg(double q) {
   const double y = __builtin_amdgcn_rsq(q);
-  double r = q * y, h = 0.5 * y;
-  const double e = __builtin_fma(-h, r, 0.5);
-  r = __builtin_fma(r, e, r);
-  h = __builtin_fma(h, e, h);
+  double r = q * y;
   const double d = __builtin_fma(-r, r, q);
-  r = __builtin_fma(d, h, r);
+  r = __builtin_fma(d, 0.5 * y, r);
   return q > 0.0 ? r : 0.0;
 }
 
