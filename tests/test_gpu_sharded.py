@@ -100,3 +100,89 @@ def test_sharded_two_ranks_device_backend_over_gloo():
         assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
         assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
     assert res[0][1:] == res[1][1:]
+
+
+def _colmajor(a, ld=None):
+    m, n = a.shape
+    ld = m if ld is None else ld
+    t = torch.zeros((n, ld), dtype=torch.float64, device="cuda")
+    t[:, :m] = torch.from_numpy(np.ascontiguousarray(a.T))
+    return t
+
+
+def test_factor_pack_panel_dev_against_numpy():
+    """bgp_factor_pack_panel_dev: diagonal-block chain + one TRSM GEMM straight into the packed buffer"""
+    import ctypes as C
+
+    from battgp_amd import _lib
+
+    rng = np.random.default_rng(3)
+    rows, nbk, ld = 2304, 512, 2400
+    g = rng.normal(size=(nbk, nbk))
+    top = g @ g.T + nbk * np.eye(nbk)
+    a = np.vstack([top, rng.normal(size=(rows - nbk, nbk))])
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    e.set_options(nb_outer=512)
+    lib = _lib.load()
+    panel = _colmajor(a, ld)
+    pack = torch.full((nbk * rows + 1,), float("nan"), dtype=torch.float64, device="cuda")
+    inv = torch.empty((nbk // 64) * 4096, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    info = C.c_int(-7)
+    rc = lib.bgp_factor_pack_panel_dev(e._h, C.c_void_p(panel.data_ptr()), ld, rows, nbk, C.c_void_p(inv.data_ptr()),
+                                       C.c_void_p(pack.data_ptr()), C.byref(info))
+    assert rc == 0 and info.value == 0
+    l11 = np.linalg.cholesky(top)
+    l21 = np.linalg.solve(l11, a[nbk:].T).T
+    got_panel = panel[:, :rows].cpu().numpy().T
+    got_pack = pack[: nbk * rows].view(nbk, rows).cpu().numpy().T
+    assert np.allclose(np.tril(got_panel[:nbk]), l11, rtol=1e-11, atol=1e-11)
+    assert np.allclose(got_panel[nbk:], l21, rtol=1e-10, atol=1e-11)
+    assert np.allclose(np.tril(got_pack[:nbk]), l11, rtol=1e-11, atol=1e-11)
+    assert np.array_equal(got_pack[nbk:], got_panel[nbk:])  # the packed copy IS what was written back
+    # a non-positive pivot is reported relative to the panel
+    bad = a.copy()
+    bad[200, 200] = -1.0
+    panel = _colmajor(bad, ld)
+    torch.cuda.synchronize()
+    rc = lib.bgp_factor_pack_panel_dev(e._h, C.c_void_p(panel.data_ptr()), ld, rows, nbk, C.c_void_p(inv.data_ptr()),
+                                       C.c_void_p(pack.data_ptr()), C.byref(info))
+    assert rc == 0 and info.value == 201
+    e.close()
+
+
+def test_update_panels_dev_against_numpy():
+    """bgp_update_panels_dev: all rank-k updates of one step in one call, launches alternating between two streams"""
+    import ctypes as C
+
+    from battgp_amd import _lib
+
+    rng = np.random.default_rng(4)
+    k, rows_p = 256, 1664  # packed panel P [rows_p, k]
+    p = rng.normal(size=(rows_p, k))
+    ld = 1800
+    # three local panels of 256 / 256 / 128 columns whose rows start at offsets 256, 768, 1280 of P
+    panels = [(0, 256, 256), (256, 256, 768), (512, 128, 1280)]  # (local col0, width, offset in P)
+    store = rng.normal(size=(ld, 640))
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    lib = _lib.load()
+    ts, tp = _colmajor(store), _colmajor(p)
+    torch.cuda.synchronize()
+    desc, want = [], store.copy()
+    for lc, w, off in panels:
+        rows_j = rows_p - off
+        r0 = 100 + off  # where this panel's diagonal sits in the store (any row offset works)
+        desc.append([lc * ld + r0, rows_j, w, off])
+        upd = p[off:] @ p[off : off + w].T
+        ti = np.arange(rows_j)[:, None] // 128
+        tj = np.arange(w)[None, :] // 128
+        blk = want[r0 : r0 + rows_j, lc : lc + w]
+        blk[ti >= tj] -= upd[ti >= tj]
+    d = np.ascontiguousarray(desc, dtype=np.int64)
+    rc = lib.bgp_update_panels_dev(e._h, C.c_void_p(ts.data_ptr()), ld, d.ctypes.data_as(C.POINTER(C.c_int64)), len(desc),
+                                   C.c_void_p(tp.data_ptr()), rows_p, k)
+    assert rc == 0
+    assert lib.bgp_sync(e._h) == 0
+    got = ts.cpu().numpy().T
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-10)
+    e.close()
