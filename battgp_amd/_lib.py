@@ -83,8 +83,8 @@ SIGNATURES = {
 }
 
 # indices of bgp_phase_times (BGP_T_* in battgp.h)
-T_H2D, T_FILL, T_POTRF, T_SOLVE, T_CROSS, T_VAR, T_D2H, T_TRAIL, T_TRAIL_FLOP, T_FILL_BYTES, T_TRAIL_LAUNCHES = range(11)
-T_COUNT = 11
+T_H2D, T_FILL, T_POTRF, T_SOLVE, T_CROSS, T_VAR, T_D2H, T_TRAIL, T_TRAIL_FLOP, T_FILL_BYTES, T_TRAIL_LAUNCHES, T_TRAIL_UNION = range(12)
+T_COUNT = 12
 
 _lib = None
 

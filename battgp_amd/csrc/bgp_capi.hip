@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
+#include <utility>
 
 #include "bgp_internal.h"
 
@@ -189,6 +191,29 @@ struct TrailTimer {
       h->times[BGP_T_TRAIL] = tot;
       h->times[BGP_T_TRAIL_FLOP] = flop;
       h->times[BGP_T_TRAIL_LAUNCHES] = (double)(used / 2);
+      // la(k) and rest(k) run on two streams at the same time: the time during which AT LEAST ONE trailing
+      // update is running (union of the launch intervals, measured against the first begin event)
+      std::vector<std::pair<float, float>> iv;
+      for (size_t e = 0; e + 1 < used; e += 2) {
+        float a = 0.f, b = 0.f;
+        BGP_HIP(h, hipEventElapsedTime(&a, h->ev_pool[0], h->ev_pool[e]));
+        BGP_HIP(h, hipEventElapsedTime(&b, h->ev_pool[0], h->ev_pool[e + 1]));
+        iv.emplace_back(a, b);
+      }
+      std::sort(iv.begin(), iv.end());
+      double uni = 0.0;
+      float lo = 0.f, hi = -1.f;
+      for (const auto& p : iv) {
+        if (hi < lo || p.first > hi) {
+          if (hi >= lo) uni += hi - lo;
+          lo = p.first;
+          hi = p.second;
+        } else if (p.second > hi) {
+          hi = p.second;
+        }
+      }
+      if (hi >= lo) uni += hi - lo;
+      h->times[BGP_T_TRAIL_UNION] = uni;
     }
     return 0;
   }

@@ -259,7 +259,7 @@ class ExactGPEngine:
         self._lib.bgp_phase_times(self._h, dptr(t), _lib.T_COUNT)
         names = [
             "h2d_ms", "fill_ms", "potrf_ms", "solve_ms", "cross_ms", "var_ms", "d2h_ms",
-            "trail_ms", "trail_flop", "fill_bytes", "trail_launches",
+            "trail_ms", "trail_flop", "fill_bytes", "trail_launches", "trail_union_ms",
         ]
         return dict(zip(names, (float(v) for v in t)))
 

@@ -296,6 +296,8 @@ def main() -> None:
                 "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": trail_tflops / PEAK_FP64_MFMA_TFLOPS,
+                "achieved_while_running": (avg["trail_flop"] / (avg["trail_union_ms"] * 1e-3) / 1e12) if avg.get("trail_union_ms", 0) > 0 else None,
+                "frac_while_running": (avg["trail_flop"] / (avg["trail_union_ms"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if avg.get("trail_union_ms", 0) > 0 else None,
                 "achieved_non_overlapped": serial,
                 "frac_non_overlapped": (serial / PEAK_FP64_MFMA_TFLOPS) if serial else None,
                 "traffic": traffic_from_profile(n, args.kernel),
@@ -304,7 +306,9 @@ def main() -> None:
                 "note": "sum of algorithmic flop m(m+1)k of the outer trailing updates / sum of their HIP-event durations "
                         "(= flop per launch / average launch duration); with look-ahead the la and rest launches of a panel "
                         "overlap each other and the next panel's factorisation, so this under-states the kernel "
-                        "(achieved_non_overlapped: the same launches in one extra untimed step with la(k) ordered before rest(k)); "
+                        "(achieved_while_running: the same flop over the UNION of the launch intervals of the timed steps, i.e. the rate "
+                        "while at least one trailing update is running; achieved_non_overlapped: the same launches in one extra "
+                        "untimed step with la(k) ordered before rest(k)); "
                         "mfma_util_pmc is SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) of the same kernel "
                         "from the serialised counter pass in profiles/",
             },

@@ -62,7 +62,8 @@ enum {
   BGP_T_TRAIL_FLOP = 8, /* algorithmic flop of those launches (2*m*n*k per full tile pair, lower half) */
   BGP_T_FILL_BYTES = 9, /* algorithmic bytes written by the last training fill */
   BGP_T_TRAIL_LAUNCHES = 10, /* number of those trailing-update launches */
-  BGP_T_COUNT = 11
+  BGP_T_TRAIL_UNION = 11, /* time during which at least one of them was running (they overlap on two streams) */
+  BGP_T_COUNT = 12
 };
 
 /* Library version (major*10000 + minor*100 + patch). */
