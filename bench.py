@@ -165,6 +165,7 @@ def main() -> None:
     ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
     ap.add_argument("--lookahead", type=int, default=-1, help="bits 0-2: look-ahead depth (0 off, 1 default); +8: panel-stream updates ordered before rest(k); +16: no atomic epilogue")
     ap.add_argument("--panel-scheme", type=int, default=-1, help="0 = 64-wide chain over all rows, 1 = diagonal-block chain + one deep TRSM GEMM (default)")
+    ap.add_argument("--slab", type=int, default=0, help="bgp_set_layout: 0 automatic, -1 full square, > 0 column-slab width")
     ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--separate", action="store_true", help="bgp_fit then bgp_predict (separate triangular-solve pass) instead of the fused call")
@@ -216,6 +217,8 @@ def main() -> None:
         eng.set_options(lookahead=args.lookahead)
     if args.panel_scheme >= 0:
         eng.set_panel_scheme(args.panel_scheme)
+    if args.slab != 0:
+        eng.set_layout(args.slab)
 
     def step():
         if args.separate:
