@@ -451,21 +451,28 @@ int ensure_part(bgp_handle* h, int64_t need);
 // (built once per fit by trinv_panels_kernel, kept on the handle): per outer panel ONE solve-by-inverse GEMM
 // into a workspace, its copy back and ONE deep update - 3 launches per panel instead of 2 per 64 columns
 // (N = 40 000, M = 300: 1250 -> 120 launches).
+// inv(L_pp) of every outer panel of the current factor, built once per fit and kept on the handle
+int ensure_panel_inverses(bgp_handle* h, hipStream_t st) {
+  const int64_t n = h->Npad, NB = h->nb_outer;
+  const int64_t npanels = (n + NB - 1) / NB;
+  if (h->LinvAll_nb == NB) return 0;
+  int rc;
+  if (h->LinvAll_cap < npanels * NB * NB) {
+    dev_free(h, &h->dLinvAll, h->LinvAll_cap);
+    h->LinvAll_cap = 0;
+    if ((rc = dev_alloc(h, &h->dLinvAll, npanels * NB * NB))) return rc;
+    h->LinvAll_cap = npanels * NB * NB;
+  }
+  if ((rc = launch_trinv_panels(h, st, h->view(), h->dInv, h->dLinvAll, n, (int)NB))) return rc;
+  h->LinvAll_nb = NB;
+  return 0;
+}
+
 int epass_inv_driver(bgp_handle* h, hipStream_t st, double* E, int64_t lde, int64_t me) {
   const int64_t n = h->Npad, NB = h->nb_outer;
   const SlabView A = h->view();
-  const int64_t npanels = (n + NB - 1) / NB;
   int rc;
-  if (h->LinvAll_nb != NB) {
-    if (h->LinvAll_cap < npanels * NB * NB) {
-      dev_free(h, &h->dLinvAll, h->LinvAll_cap);
-      h->LinvAll_cap = 0;
-      if ((rc = dev_alloc(h, &h->dLinvAll, npanels * NB * NB))) return rc;
-      h->LinvAll_cap = npanels * NB * NB;
-    }
-    if ((rc = launch_trinv_panels(h, st, A, h->dInv, h->dLinvAll, n, (int)NB))) return rc;
-    h->LinvAll_nb = NB;
-  }
+  if ((rc = ensure_panel_inverses(h, st))) return rc;
   if ((rc = ensure_part(h, me * NB))) return rc;  // the solved block before it is copied back (ld = me)
   double* W = h->dpart;
   for (int64_t K0 = 0, p = 0; K0 < n; K0 += NB, ++p) {
@@ -497,6 +504,9 @@ int backward_driver(bgp_handle* h, hipStream_t st) {
   const SlabView V = h->view();
   int rc = ensure_part(h, ((n + 1023) / 1024 + 1) * NB);
   if (rc) return rc;
+  // from three outer panels on: the diagonal blocks by their explicit inverses (one GEMV each)
+  const bool by_inverse = n > 2 * NB;
+  if (by_inverse && (rc = ensure_panel_inverses(h, st))) return rc;
   const int64_t nblk = (n + NB - 1) / NB;
   for (int64_t b = nblk - 1; b >= 0; --b) {
     const int64_t K0 = b * NB;
@@ -507,8 +517,11 @@ int backward_driver(bgp_handle* h, hipStream_t st) {
       rc = launch_gemv_t_partial(h, st, V.at(K1, K0), V.ld(K0), h->dalpha + K1, n - K1, (int)nbk, h->dpart, &nch);
       if (rc) return rc;
     }
-    rc = launch_trsv_block_bwd(h, st, V.at(K0, K0), V.ld(K0), h->dInv + (K0 / BGP_IB) * (BGP_IB * BGP_IB),
-                               h->dz + K0, h->dpart, nch, (int)nbk, h->dalpha + K0);
+    if (by_inverse)
+      rc = launch_linvT_gemv(h, st, h->dLinvAll + b * NB * NB, NB, h->dz + K0, h->dpart, nch, (int)nbk, h->dalpha + K0);
+    else
+      rc = launch_trsv_block_bwd(h, st, V.at(K0, K0), V.ld(K0), h->dInv + (K0 / BGP_IB) * (BGP_IB * BGP_IB),
+                                 h->dz + K0, h->dpart, nch, (int)nbk, h->dalpha + K0);
     if (rc) return rc;
   }
   return 0;

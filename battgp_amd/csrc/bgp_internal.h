@@ -157,6 +157,8 @@ int launch_gemv_t_partial(bgp_handle* h, hipStream_t st, const double* P, int64_
                           int64_t rows, int nbk, double* part, int* nchunks_out);
 int launch_trsv_block_bwd(bgp_handle* h, hipStream_t st, const double* Lkk, int64_t lda, const double* invK,
                           const double* z, const double* part, int nchunks, int nbk, double* alpha);
+int launch_linvT_gemv(bgp_handle* h, hipStream_t st, const double* Linv, int64_t ldl, const double* z, const double* part,
+                      int nchunks, int nbk, double* alpha);
 int launch_rowdot(bgp_handle* h, hipStream_t st, const double* E, int64_t lde, int64_t M, int64_t n,
                   const double* vec /*null => E*E*/, double* part, int* nchunks_out);
 int launch_rowdot_finish(bgp_handle* h, hipStream_t st, const double* part, int nchunks, int64_t M,

@@ -593,6 +593,29 @@ __global__ __launch_bounds__(512) void trsv_block_bwd_kernel(const double* __res
   for (int c = tid; c < nbk; c += 512) alpha[c] = sw[c];
 }
 
+// alpha_K = inv(L_KK)^T (z_K - sum_chunks part): the diagonal block's share of the backward solve as ONE
+// GEMV with the explicit panel inverse (one wave per column, coalesced down the column) instead of a
+// single-workgroup substitution over the 64 x 64 tiles (0.5 ms per 1024-wide panel).
+__global__ __launch_bounds__(256) void linvT_gemv_kernel(const double* __restrict__ Linv, int64_t ldl,
+                                                         const double* __restrict__ z, const double* __restrict__ part,
+                                                         int nchunks, int nbk, double* __restrict__ alpha) {
+  __shared__ double sw[TRSV_MAX_NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < nbk; c += 256) {
+    double v = z[c];
+    for (int q = 0; q < nchunks; ++q) v -= part[(int64_t)q * nbk + c];
+    sw[c] = v;
+  }
+  __syncthreads();
+  const int c = (int)blockIdx.x * 4 + wave;  // alpha_c = sum_{r >= c} Linv(r, c) w_r
+  if (c >= nbk) return;
+  const double* col = Linv + (int64_t)c * ldl;
+  double acc = 0.0;
+  for (int r = c - (c & 63) + lane; r < nbk; r += 64) acc = __builtin_fma(r >= c ? col[r] : 0.0, sw[r], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) alpha[c] = acc;
+}
+
 // ---- row-wise reductions over the query block E[M, n] (column-major, rows contiguous) ---------
 // part[chunk][m] = sum_{i in chunk} E[m,i] * (vec ? vec[i] : E[m,i])
 constexpr int RD_COLS = BGP_RD_COLS;  // 128: four times the workgroups of a 512-column chunk on a latency-bound pass
@@ -850,6 +873,15 @@ int launch_trsv_block_bwd(bgp_handle* h, hipStream_t st, const double* Lkk, int6
                           const double* z, const double* part, int nchunks, int nbk, double* alpha) {
   if (nbk > TRSV_MAX_NB) return bgp_fail(h, -1, "nb_outer=%d exceeds the TRSV limit %d", nbk, TRSV_MAX_NB);
   hipLaunchKernelGGL(trsv_block_bwd_kernel, dim3(1), dim3(512), 0, st, Lkk, lda, invK, z, part, nchunks, nbk,
+                     alpha);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_linvT_gemv(bgp_handle* h, hipStream_t st, const double* Linv, int64_t ldl, const double* z, const double* part,
+                      int nchunks, int nbk, double* alpha) {
+  if (nbk > TRSV_MAX_NB) return bgp_fail(h, -1, "nb_outer=%d exceeds the TRSV limit %d", nbk, TRSV_MAX_NB);
+  hipLaunchKernelGGL(linvT_gemv_kernel, dim3((unsigned)((nbk + 3) / 4)), dim3(256), 0, st, Linv, ldl, z, part, nchunks, nbk,
                      alpha);
   BGP_HIP(h, hipGetLastError());
   return 0;
