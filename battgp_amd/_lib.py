@@ -46,6 +46,8 @@ SIGNATURES = {
     "bgp_kernel_matrix": (C.c_int, [handle_p, c_double_p, C.c_int64, c_double_p, C.c_int64, C.c_int, c_double_p]),
     "bgp_get_alpha": (C.c_int, [handle_p, c_double_p]),
     "bgp_residuals": (C.c_int, [handle_p, C.c_int, c_double_p]),
+    "bgp_get_factor_rows": (C.c_int, [handle_p, C.POINTER(C.c_int64), C.c_int, c_double_p]),
+    "bgp_get_factor_diag": (C.c_int, [handle_p, c_double_p]),
     "bgp_phase_times": (C.c_int, [handle_p, c_double_p, C.c_int]),
     "bgp_device_bytes": (C.c_int64, [handle_p]),
     "bgp_potrf_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, c_int_p]),

@@ -1,18 +1,25 @@
-"""``BatteryCellGP_Full`` / ``build_cellmodel_full`` - the per-cell plugin of the ``full_gp`` mode.
+"""Per-cell plugin of the ``full_gp`` mode on MI355X: ``BatteryCellGP_Full`` and ``build_cellmodel_full``.
 
-Same public surface as the reference's ``src/batt_models/battcellgp_full.py:46-240`` (an
-``IBatteryCellGP``, ``src/batt_models/batt_cell_gp_protocol.py:9-86``): numpy ``[N, 4]`` / ``[N]``
-in, numpy / pandas out, so ``BattGP_Full`` (``src/batt_models/battgp_full.py:41-125``),
-``BattGP.train_hyperparameters`` / ``save_hyperparameters`` (``src/batt_models/battgp.py:181-225``)
-and the plotting helpers consume it unchanged - with the GP algebra running on MI355X through
-libbattgp.so instead of gpytorch.
+Written against the CONTRACT the reference's callers rely on, not against the reference's implementation:
+
+* the ``IBatteryCellGP`` protocol (``src/batt_models/batt_cell_gp_protocol.py:9-86``): numpy ``[N, 4]`` inputs in
+  the order (time [d], current [A], SOC [%], temperature [degC]), numpy ``[N]`` target, the seven methods below;
+* the keyword names a caller may pass and read back (``src/batt_models/battcellgp_full.py:94-111``), the CSV row
+  labels of a saved hyper-parameter file (``:25-32`` + "Marginal Likelihood") and the result column names
+  ``t`` / ``r0_acausal_<tag>`` / ``r0var_acausal_<tag>`` (``:212-218``) - kept below as DATA TABLES;
+* what ``BattGP_Full`` touches on a cell model (``src/batt_models/battgp_full.py:41-125``): ``.model`` (deletable,
+  with ``train_inputs[0]`` / ``train_targets``), ``.cellnr``, ``predict_r0_op(op=, t=)``.
+
+All GP algebra runs in libbattgp.so (HIP, gfx950) through :class:`battgp_amd.cell_gp.BatteryCellGP`; when a GPU is
+visible the training tensors live on it and a prediction moves only the 4 M query doubles up and 2 M results down.
 """
 
 from __future__ import annotations
 
+import copy
 import os
-from copy import deepcopy
-from typing import Any, Optional
+from dataclasses import dataclass
+from typing import Any, Callable, Optional
 
 import numpy as np
 import pandas as pd
@@ -22,35 +29,81 @@ from . import config as cfg
 from . import training
 from .cell_gp import BatteryCellGP
 from .engine import as_device_index
-from .operating_point import Op, get_causal_tag, get_cell_tag
 
 
-def _create_hyperparams_df(params: dict) -> pd.DataFrame:
-    """Row labels and order of ``battcellgp_full.py:21-43``."""
-    return pd.DataFrame(
-        index=[
-            "Noise Variance",
-            "Wiener Outputscale",
-            "RBF Outputscale",
-            "RBF Lengthscale 1",
-            "RBF Lengthscale 2",
-            "RBF Lengthscale 3",
-        ],
-        columns=["params"],
-        data=[
-            [params["noise_variance"]],
-            [params["outputscale_wiener"]],
-            [params["outputscale_rbf"]],
-            [params["lengthscale_rbf"][0]],
-            [params["lengthscale_rbf"][1]],
-            [params["lengthscale_rbf"][2]],
-        ],
-    )
+# ---- the contract, as data ---------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class _HyperSpec:
+    key: str  # keyword / params key; the model property of the same name holds the value
+    labels: tuple  # CSV row label per component
+    default: Any
+    default_range: Any
+
+    @property
+    def range_key(self) -> str:
+        return f"{self.key}_range"
+
+    @property
+    def constraint_attr(self) -> str:
+        return f"{self.key}_constraint"
 
 
-def _resolve_device(device) -> torch.device:
-    """The reference defaults to CPU; this engine has no CPU path, so "not given" means GPU 0 and an
-    explicit CPU device is an error raised when the first computation needs the engine."""
+_HYPERS = (
+    _HyperSpec("noise_variance", ("Noise Variance",), cfg.NOISE_VARIANCE, cfg.NOISE_VARIANCE_RANGE),
+    _HyperSpec("outputscale_wiener", ("Wiener Outputscale",), cfg.OUTPUTSCALE_WIENER, cfg.OUTPUTSCALE_WIENER_RANGE),
+    _HyperSpec("outputscale_rbf", ("RBF Outputscale",), cfg.OUTPUTSCALE_RBF, cfg.OUTPUTSCALE_RBF_RANGE),
+    _HyperSpec(
+        "lengthscale_rbf", ("RBF Lengthscale 1", "RBF Lengthscale 2", "RBF Lengthscale 3"), cfg.LENGTHSCALE_RBF, cfg.LENGTHSCALE_RBF_RANGE
+    ),
+)
+# keyword -> (default, name of the trainer argument it feeds; None = not a trainer argument)
+_SETTINGS = {
+    "max_iter": (cfg.OPTIM_MAX_ITER, "max_iter"),
+    "rel_tol": (cfg.OPTIM_REL_TOL, "rel_ftol"),
+    "lr": (cfg.OPTIM_LR, "lr"),
+    "dtype": (cfg.DTYPE, None),
+    "n_devices": (1, None),
+    "output_device": (None, None),
+}
+_NOT_RECORDED = frozenset({"device"})  # accepted keywords that never appear in get_parameters()
+_LML_ROW = "Marginal Likelihood"
+_TRAINERS: dict[str, Callable] = {
+    "torch_adam": training.train_exact_gp_adam,
+    "torch_lbfgs": training.train_exact_gp_lbfgs,
+    "botorch_lbfgs_B": training.train_exact_gp_botorch,
+}
+
+
+def _series_tag(cellnr) -> str:
+    """``pack`` for the pack model (cell number -1), ``c<n>`` for a cell (``src/batt_models/cellnr.py:4-8``)."""
+    return "pack" if cellnr == -1 else f"c{cellnr}"
+
+
+def _flat(value) -> list:
+    """Components of a hyper-parameter: tuples / arrays as they are, ``(2.33e-6,)`` and ``2.33e-6`` alike."""
+    return list(np.atleast_1d(np.asarray(value, dtype=object)).ravel())
+
+
+def hyperparameter_table(params: dict, lml=None) -> pd.DataFrame:
+    """One row per hyper-parameter component, column ``params`` - the layout of ``<cellnr>hyperparams.csv``."""
+    labels, values = [], []
+    for spec in _HYPERS:
+        comps = _flat(params[spec.key])
+        if len(spec.labels) == 1:
+            comps = [params[spec.key]]  # a scalar (or the reference's 1-tuple noise) is stored as given
+        for label, comp in zip(spec.labels, comps):
+            labels.append(label)
+            values.append(comp)
+    table = pd.DataFrame({"params": pd.Series(values, index=labels, dtype=object)})
+    if lml is not None:
+        table.loc[_LML_ROW] = lml
+    return table
+
+
+def _torch_device(device) -> torch.device:
+    """``device=`` as the callers pass it: ``None``, an index (``gp_runner.py:162-171``), a string or a
+    ``torch.device``.  There is no CPU engine: "not given" means GPU 0 (the reference's default is the CPU), and an
+    explicit CPU device fails when the first computation asks for the engine."""
     if device is None:
         return torch.device("cuda", 0)
     if isinstance(device, (int, np.integer)):
@@ -59,195 +112,144 @@ def _resolve_device(device) -> torch.device:
 
 
 class BatteryCellGP_Full:
-    def __init__(self, x: np.ndarray, y: np.ndarray, cellnr: Optional[int] = None, **kwargs):
-        self.params: dict[str, Any] = self.get_default_parameters()
-        self._cellnr = cellnr
+    """``IBatteryCellGP`` for one cell (or the pack): exact GP with the Wiener + ARD-RBF kernel on one MI355X."""
 
-        UNLOGGED_PARAMS = {"device"}
-        for k, v in kwargs.items():
-            if k in UNLOGGED_PARAMS:
-                continue
-            if k not in self.params:
-                raise ValueError(f"unknown keyword parameter '{k}'")
-            self.params[k] = v
+    def __init__(self, x: np.ndarray, y: np.ndarray, cellnr: Optional[int] = None, **kwargs):
+        self._cellnr = cellnr
+        self.params: dict[str, Any] = self.get_default_parameters()
+        for name in kwargs:
+            if name not in self.params and name not in _NOT_RECORDED:
+                raise ValueError(f"unknown keyword parameter '{name}'")
+        self.params.update({k: v for k, v in kwargs.items() if k not in _NOT_RECORDED})
 
         self.dtype_ = self.params["dtype"]
         if self.dtype_ != torch.float64:
             raise ValueError("battgp_amd computes the full_gp path in fp64 only (cfg.DTYPE)")
-        self.device_ = _resolve_device(kwargs.get("device", None))
+        self.device_ = _torch_device(kwargs.get("device"))
 
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
         if x.ndim != 2 or x.shape[0] != y.shape[0]:
             raise ValueError("x must be [N, 4] and y [N]")
-        # torch tensors are the containers the callers expect (train_inputs[0][:, 0], .detach().cpu());
-        # they live on the GPU when one is visible so the fit can adopt them without a host copy
-        on_gpu = self.device_.type == "cuda" and torch.cuda.is_available()
-        tdev = self.device_ if on_gpu else torch.device("cpu")
-        xt = torch.tensor(x, dtype=self.dtype_, device=tdev)
-        yt = torch.tensor(y, dtype=self.dtype_, device=tdev)
-
+        # the containers the callers read (train_inputs[0][:, 0].detach().cpu()) live on the GPU when there is one,
+        # so the engine adopts them without a host copy
+        home = self.device_ if (self.device_.type == "cuda" and torch.cuda.is_available()) else torch.device("cpu")
         self.model: BatteryCellGP = BatteryCellGP(
-            xt,
-            yt,
+            torch.from_numpy(x).to(home),
+            torch.from_numpy(y).to(home),
             n_devices=self.params["n_devices"],
             output_device=self.params["output_device"],
             device=self.device_,
         )
-        self.model.noise_variance_constraint = self.params["noise_variance_range"]
-        self.model.noise_variance = self.params["noise_variance"]
-        self.model.outputscale_wiener_constraint = self.params["outputscale_wiener_range"]
-        self.model.outputscale_wiener = self.params["outputscale_wiener"]
-        self.model.outputscale_rbf_constraint = self.params["outputscale_rbf_range"]
-        self.model.outputscale_rbf = self.params["outputscale_rbf"]
-        self.model.lengthscale_rbf_constraint = self.params["lengthscale_rbf_range"]
-        self.model.lengthscale_rbf = self.params["lengthscale_rbf"]
+        for spec in _HYPERS:  # range first: the value is stored through the constraint's transform
+            setattr(self.model, spec.constraint_attr, self.params[spec.range_key])
+            setattr(self.model, spec.key, self.params[spec.key])
         self.model.eval()
         self.model.likelihood.eval()
 
+    # -- identity / parameters ------------------------------------------------------------------------------
     @property
     def cellnr(self) -> int:
         return self._cellnr
 
-    def __delattr__(self, name):
-        # ``del cellmodel.model`` (src/batt_models/battgp_full.py:103,118) must release the engine handle and
-        # its HBM at once, without waiting for the garbage collector
-        if name == "model":
-            mdl = self.__dict__.get("model")
-            if mdl is not None:
-                mdl.close()
-        super().__delattr__(name)
-
     @staticmethod
     def get_default_parameters() -> dict[str, Any]:
-        return {
-            "noise_variance": cfg.NOISE_VARIANCE,
-            "outputscale_wiener": cfg.OUTPUTSCALE_WIENER,
-            "outputscale_rbf": cfg.OUTPUTSCALE_RBF,
-            "lengthscale_rbf": cfg.LENGTHSCALE_RBF,
-            "noise_variance_range": cfg.NOISE_VARIANCE_RANGE,
-            "outputscale_wiener_range": cfg.OUTPUTSCALE_WIENER_RANGE,
-            "outputscale_rbf_range": cfg.OUTPUTSCALE_RBF_RANGE,
-            "lengthscale_rbf_range": cfg.LENGTHSCALE_RBF_RANGE,
-            "max_iter": cfg.OPTIM_MAX_ITER,
-            "rel_tol": cfg.OPTIM_REL_TOL,
-            "lr": cfg.OPTIM_LR,
-            "dtype": cfg.DTYPE,
-            "n_devices": 1,
-            "output_device": None,
-        }
+        out: dict[str, Any] = {spec.key: spec.default for spec in _HYPERS}
+        out.update({spec.range_key: spec.default_range for spec in _HYPERS})
+        out.update({key: default for key, (default, _) in _SETTINGS.items()})
+        return out
 
     def get_parameters(self) -> dict[str, Any]:
-        return deepcopy(self.params)
+        return copy.deepcopy(self.params)
 
     def save_hyperparameters(self, path: str) -> None:
-        hyperparams_df = _create_hyperparams_df(self.params)
-        hyperparams_df.loc["Marginal Likelihood"] = self.marginallikelihood
-        path = os.path.join(path, f"{self._cellnr}hyperparams.csv")
-        hyperparams_df.to_csv(path)
+        table = hyperparameter_table(self.params, lml=self.marginallikelihood)
+        table.to_csv(os.path.join(path, f"{self._cellnr}hyperparams.csv"))
 
+    # -- training -------------------------------------------------------------------------------------------
     def train_hyperparameters(self, messages: bool = True) -> np.ndarray:
-        x_train = self.model.train_inputs[0]
-        y_train = self.model.train_targets
-
+        """Optimise the hyper-parameters with the algorithm named in ``cfg.HYPER_OPT_PARAMS`` (each iteration = one
+        resident re-fit + one gradient pass on the GPU), write the optimum back into ``params`` and remember the
+        final loss (``-mll * N``) as ``marginallikelihood``."""
         algo = cfg.HYPER_OPT_PARAMS["opt_algorithm"]
-        if algo == "torch_lbfgs":
-            trainer = training.train_exact_gp_lbfgs
-        elif algo == "botorch_lbfgs_B":
-            trainer = training.train_exact_gp_botorch
-        elif algo == "torch_adam":
-            trainer = training.train_exact_gp_adam
-        else:
+        if algo not in _TRAINERS:
             raise ValueError(f"{algo} is not implemented as optimization algorithm.")
-
-        losses = trainer(
-            self.model,
-            x_train,
-            y_train,
-            loss_scale=len(y_train),
-            max_iter=self.params["max_iter"],
-            rel_ftol=self.params["rel_tol"],
-            lr=self.params["lr"],
-            messages=messages,
+        trainer_args = {arg: self.params[key] for key, (_, arg) in _SETTINGS.items() if arg is not None}
+        targets = self.model.train_targets
+        history = _TRAINERS[algo](
+            self.model, self.model.train_inputs[0], targets, loss_scale=len(targets), messages=messages, **trainer_args
         )
+        for spec in _HYPERS:
+            learned = getattr(self.model, spec.key).detach().cpu().numpy().ravel()
+            if len(spec.labels) > 1:
+                self.params[spec.key] = tuple(learned)
+            else:
+                self.params[spec.key] = float(learned[0])
+        self.marginallikelihood = history[-1] if isinstance(history, np.ndarray) else history
+        return history
 
-        self.params["noise_variance"] = float(self.model.noise_variance)
-        self.params["outputscale_wiener"] = float(self.model.outputscale_wiener)
-        self.params["outputscale_rbf"] = float(self.model.outputscale_rbf)
-        self.params["lengthscale_rbf"] = tuple(self.model.lengthscale_rbf.detach().cpu().numpy()[0])
-
-        if isinstance(losses, np.ndarray):
-            self.marginallikelihood = losses[-1]
-        else:
-            self.marginallikelihood = losses
-        return losses
-
+    # -- prediction -----------------------------------------------------------------------------------------
     def predict(self, x: np.ndarray, full_cov: bool = False, no_cov: bool = False):
+        """Posterior of the latent resistance at ``x [M, 4]``: ``mean`` alone (``no_cov``), ``(mean, var [M])``, or
+        ``(mean, [M, M])`` with ``full_cov`` - which, like the reference, carries only the marginal variances on
+        the diagonal of an otherwise-NaN matrix."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         if no_cov:
-            # mean only: cross fill + GEMV against the cached alpha, no triangular solve
-            return self.model.posterior_mean(x)
-        out = self.model(torch.as_tensor(x))
-        y = out.mean.detach().cpu().numpy()
-        y_var = out.variance.detach().cpu().numpy().reshape(-1)
-        if full_cov:
-            # the reference returns a NaN matrix with only the diagonal filled (battcellgp_full.py:182-193)
-            n = x.shape[0]
-            covmatrix = np.full((n, n), np.nan, dtype=np.float64)
-            covmatrix[np.diag_indices(n)] = y_var
-            y_var = covmatrix
-        return (y, y_var)
+            return self.model.posterior_mean(x)  # cross fill + GEMV against alpha, no triangular solve
+        mean, var = (t.detach().cpu().numpy().reshape(-1) for t in self.model.posterior(x))
+        if not full_cov:
+            return mean, var
+        square = np.full((len(var), len(var)), np.nan, dtype=np.float64)
+        np.fill_diagonal(square, var)
+        return mean, square
 
-    def predict_r0_op(self, op: Op, t: np.ndarray) -> pd.DataFrame:
-        t = np.asarray(t, dtype=np.float64)
-        X = np.column_stack((t, np.ones(len(t)) * op.I, np.ones(len(t)) * op.SOC, np.ones(len(t)) * op.T))
-        (r0, r0var) = self.predict(X, full_cov=False)
-        cell_tag = get_cell_tag(self._cellnr)
-        causal_tag = get_causal_tag(False)
-        return pd.DataFrame(
-            {
-                "t": t,
-                f"r0_{causal_tag}_{cell_tag}": r0,
-                f"r0var_{causal_tag}_{cell_tag}": r0var,
-            }
-        )
+    def predict_r0_op(self, op, t: np.ndarray) -> pd.DataFrame:
+        """Resistance over time at the operating point ``op`` (anything with ``.I``, ``.SOC``, ``.T``)."""
+        t = np.asarray(t, dtype=np.float64).reshape(-1)
+        query = np.empty((t.size, 4), dtype=np.float64)
+        query[:, 0] = t
+        query[:, 1:] = (op.I, op.SOC, op.T)
+        r0, r0_var = self.predict(query)
+        tag = f"acausal_{_series_tag(self._cellnr)}"
+        return pd.DataFrame({"t": t, f"r0_{tag}": r0, f"r0var_{tag}": r0_var})
 
     def get_training_data(self) -> tuple[np.ndarray, np.ndarray]:
-        return (
-            self.model.train_inputs[0].detach().cpu().numpy(),
-            self.model.train_targets.detach().cpu().numpy().reshape((-1,)),
-        )
+        x, y = self.model.train_inputs[0], self.model.train_targets
+        return x.detach().cpu().numpy(), y.detach().cpu().numpy().reshape(-1)
+
+    # -- lifetime -------------------------------------------------------------------------------------------
+    def __delattr__(self, name):
+        # ``del cellmodel.model`` (src/batt_models/battgp_full.py:103,118) must give the engine handle and its HBM
+        # back at once, without waiting for the garbage collector
+        if name == "model":
+            held = self.__dict__.get("model")
+            if held is not None:
+                held.close()
+        super().__delattr__(name)
 
 
-def build_cellmodel_full(
-    cellnr: int,
-    batt_data,
-    max_training_data: int,
-    max_age: Optional[int] = None,
-    device=None,
-    **kwargs,
-) -> BatteryCellGP_Full:
-    """``src/batt_models/battcellgp_full.py:229-240``: ``batt_data`` is anything with the
-    reference's ``generateTrainingData(cellnr, max_training_data, max_age) -> (X[N,4], y[N])``."""
-    (x, y) = batt_data.generateTrainingData(cellnr, max_training_data, max_age)
+def build_cellmodel_full(cellnr: int, batt_data, max_training_data: int, max_age: Optional[int] = None, device=None, **kwargs):
+    """Factory used by ``BattGP_Full`` (``src/batt_models/battgp_full.py:41-60``): ``batt_data`` is anything with the
+    reference's ``generateTrainingData(cellnr, max_training_data, max_age) -> (X[N, 4], y[N])``."""
+    x, y = batt_data.generateTrainingData(cellnr, max_training_data, max_age)
     return BatteryCellGP_Full(x, y, cellnr, device=device, **kwargs)
 
 
-def predict_cells_concurrently(cellmodels, op: Op, t: np.ndarray) -> list[pd.DataFrame]:
-    """One GP per GPU, concurrently: models bound to different devices
-    are driven from one thread each - the C-ABI calls release the GIL and distinct handles are
-    independent.  Models that share a device run one after another on that device's thread."""
+def predict_cells_concurrently(cellmodels, op, t: np.ndarray) -> list[pd.DataFrame]:
+    """One GP per GPU, concurrently: models bound to different devices are driven
+    from one thread each - the C-ABI calls release the GIL and distinct handles are independent.  Models that
+    share a device run one after another on that device's thread."""
     from concurrent.futures import ThreadPoolExecutor
 
-    by_dev: dict[int, list[int]] = {}
+    lanes: dict[int, list[int]] = {}
     for i, mdl in enumerate(cellmodels):
-        by_dev.setdefault(as_device_index(mdl.device_), []).append(i)
-    out: list[Optional[pd.DataFrame]] = [None] * len(cellmodels)
+        lanes.setdefault(as_device_index(mdl.device_), []).append(i)
+    frames: list[Optional[pd.DataFrame]] = [None] * len(cellmodels)
 
-    def run(idxs):
-        for i in idxs:
-            out[i] = cellmodels[i].predict_r0_op(op, t)
+    def drive(indices):
+        for i in indices:
+            frames[i] = cellmodels[i].predict_r0_op(op, t)
 
-    with ThreadPoolExecutor(max_workers=max(1, len(by_dev))) as pool:
-        list(pool.map(run, by_dev.values()))
-    return out
+    with ThreadPoolExecutor(max_workers=max(1, len(lanes))) as pool:
+        list(pool.map(drive, lanes.values()))
+    return frames

@@ -184,8 +184,11 @@ class BattGP_Full:
             with ThreadPoolExecutor(len(groups)) as pool:
                 list(pool.map(run, groups))
         # every frame carries the same time grid self.t, so the reference's chain of DataFrame.merge() calls on
-        # "t" (battgp_full.py:100-121; ~1 ms each) is a column-wise concatenation
-        if all(np.array_equal(f["t"].to_numpy(), frames[0]["t"].to_numpy()) for f in frames[1:]):
+        # "t" (battgp_full.py:100-121; ~1 ms each) is a column-wise concatenation - as long as the grid has no
+        # repeated time stamps: on repeated keys merge() yields their cross product (add_time_steps=True repeats
+        # t_train[0], the start of the linspace), and the callers downstream get exactly that frame here too
+        unique_grid = np.unique(self.t).size == self.t.size
+        if unique_grid and all(np.array_equal(f["t"].to_numpy(), frames[0]["t"].to_numpy()) for f in frames[1:]):
             df = pd.concat([frames[0]] + [f.drop(columns="t") for f in frames[1:]], axis=1)
         else:
             df = frames[0]

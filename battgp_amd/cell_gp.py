@@ -175,15 +175,22 @@ class BatteryCellGP:
     ):
         if n_devices < 1:
             raise ValueError("n_devices must be an integer and >= 1")  # cell_gp.py:47
-        self.n_devices = n_devices
+        self.n_devices = int(n_devices)
         self.output_device = output_device
+        # n_devices > 1 in the reference = ONE GP whose kernel matrix is spread over several GPUs
+        # (MultiDeviceKernel, cell_gp.py:37-43).  Here that is the sharded Cholesky (battgp_amd/sharded.py), which
+        # runs one process per GPU: the caller must already be inside a torch.distributed group of that size.
+        self._sharded = None
+        if self.n_devices > 1:
+            self._require_process_group()
         x = torch.as_tensor(train_x, dtype=torch.float64)
         y = torch.as_tensor(train_y, dtype=torch.float64).reshape(-1)
         if x.ndim != 2 or x.shape[0] != y.shape[0]:
             raise ValueError("train_x must be [N, D] and train_y [N]")
         self.device_ = device if device is not None else x.device
-        self.train_inputs = (x.contiguous(),)
-        self.train_targets = y.contiguous()
+        self._resident = False  # X, y of THIS object are in the engine's HBM (cleared when they are replaced)
+        self._train_inputs = (x.contiguous(),)
+        self._train_targets = y.contiguous()
         d = x.shape[1]
         # GPyTorch defaults before the adaptor overwrites them (softplus(0) = ln 2)
         self._noise = math.log(2.0)
@@ -200,6 +207,48 @@ class BatteryCellGP:
         self._fitted = False
         self.lml = None
         self.jitter = None
+
+    # -- training data (what the callers read; replacing it invalidates the copy in HBM) --------------------
+    @property
+    def train_inputs(self):
+        return self._train_inputs
+
+    @train_inputs.setter
+    def train_inputs(self, value):
+        value = value if isinstance(value, (tuple, list)) else (value,)
+        self._train_inputs = tuple(torch.as_tensor(v, dtype=torch.float64).contiguous() for v in value)
+        self._resident = False
+        self._invalidate()
+
+    @property
+    def train_targets(self):
+        return self._train_targets
+
+    @train_targets.setter
+    def train_targets(self, value):
+        self._train_targets = torch.as_tensor(value, dtype=torch.float64).reshape(-1).contiguous()
+        self._resident = False
+        self._invalidate()
+
+    def set_train_data(self, inputs=None, targets=None, strict: bool = True):
+        """``ExactGP.set_train_data``: swap the data, keep the hyper-parameters."""
+        if inputs is not None:
+            self.train_inputs = inputs
+        if targets is not None:
+            self.train_targets = targets
+
+    def _require_process_group(self):
+        import torch.distributed as dist
+
+        from .engine import EngineError
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != self.n_devices:
+            raise EngineError(
+                f"n_devices={self.n_devices} spreads ONE GP over {self.n_devices} GPUs: in battgp_amd that is the sharded "
+                f"Cholesky, one process per GPU - launch the caller with `python -m torch.distributed.run "
+                f"--nproc-per-node {self.n_devices} ...` (battgp_amd/sharded.py); n_devices=1 is the single-GPU engine"
+            )
+        return dist
 
     # -- module plumbing ------------------------------------------------------------------------
     def to(self, device):
@@ -272,56 +321,137 @@ class BatteryCellGP:
             self._engine = ExactGPEngine(KERNEL_BATTGP, self.hyp_vector(), device=as_device_index(self.device_))
         return self._engine
 
+    def _train_on_engine_device(self, eng: ExactGPEngine) -> bool:
+        x = self._train_inputs[0]
+        return bool(x.is_cuda and x.device.index == eng.device_index and self._train_targets.is_cuda)
+
+    def _shard(self):
+        """The sharded engine of an ``n_devices > 1`` model (one rank of it)."""
+        if self._sharded is None:
+            from .sharded import make_sharded_gp
+
+            dist = self._require_process_group()
+            self._sharded = make_sharded_gp(KERNEL_BATTGP, self.hyp_vector(), backend_name=dist.get_backend())
+        return self._sharded
+
     def fit(self) -> float:
-        """Fill + jittered Cholesky + alpha + LML on the GPU (cached until a hyper-parameter
-        changes) - the work GPyTorch does lazily inside the first ``model(x)`` / ``mll`` call."""
+        """Fill + jittered Cholesky + LML on the GPU (cached until a hyper-parameter or the data changes) - the
+        work GPyTorch does lazily inside the first ``model(x)`` / ``mll`` call."""
+        if self._fitted:
+            return self.lml
+        x, y = self._train_inputs[0], self._train_targets
+        if self.n_devices > 1:
+            gp = self._shard()
+            gp.set_hyp(self.hyp_vector())
+            self.lml = gp.fit(x.detach().cpu().numpy(), y.detach().cpu().numpy())
+            self.jitter = gp.jitter
+            self._fitted = True
+            return self.lml
         eng = self.engine()
-        if not self._fitted:
-            x, y = self.train_inputs[0], self.train_targets
-            if eng.n == x.shape[0] and eng.d == x.shape[1] and eng.n > 0:
-                self.lml = eng.refit(self.hyp_vector())  # X, y already resident in HBM
+        try:
+            if self._resident:
+                self.lml = eng.refit(self.hyp_vector())  # X, y of this object already in HBM
             else:
                 eng.set_hyp(self.hyp_vector())
-                if x.is_cuda and x.device.index == eng.device_index:
+                if self._train_on_engine_device(eng):
                     torch.cuda.current_stream(x.device).synchronize()
                     self.lml = eng.fit_device(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1])
                 else:
-                    self.lml = eng.fit(x.cpu().numpy(), y.cpu().numpy())
-            self.jitter = eng.jitter
-            self._fitted = True
+                    self.lml = eng.fit(x.detach().cpu().numpy(), y.detach().cpu().numpy())
+        except Exception:
+            self._resident = False  # a failed call may have dropped the resident problem: upload again next time
+            raise
+        self._resident = True
+        self.jitter = eng.jitter
+        self._fitted = True
         return self.lml
 
-    def __call__(self, x) -> Posterior:
+    def posterior(self, x, want_var: bool = True):
+        """Posterior mean and variance of the latent f at ``x`` as two tensors on the query's device.  First call on
+        an unfitted model = ONE fused pass (the query rows ride through the factorisation, ``bgp_fit_predict``) -
+        the reference builds K lazily and factorises inside the first ``model(x)`` (``battcellgp_full.py:171-173``).
+        When the training tensors live on the engine's GPU nothing crosses PCIe but the 2 x M results."""
         xq = torch.as_tensor(x, dtype=torch.float64)
-        xq_host = xq.detach().cpu().numpy()
-        if not self._fitted:
-            # the reference builds K lazily and factorises inside the first model(x) call
-            # (battcellgp_full.py:171-173): do the same in ONE pass - the query rows ride through the
-            # factorisation (bgp_fit_predict), no separate triangular solve
-            eng = self.engine()
-            eng.set_hyp(self.hyp_vector())
-            xt, yt = self.train_inputs[0], self.train_targets
-            self.lml, mean, var = eng.fit_predict(xt.cpu().numpy(), yt.cpu().numpy(), xq_host, True, MIN_VARIANCE)
+        if xq.ndim == 1:
+            xq = xq.reshape(-1, self._train_inputs[0].shape[1])
+        if self.n_devices > 1:
+            self.fit()
+            mean, var = self._shard().predict(xq.detach().cpu().numpy(), min_var=MIN_VARIANCE)
+            return torch.as_tensor(mean, device=xq.device), torch.as_tensor(var, device=xq.device)
+        eng = self.engine()
+        xt, yt = self._train_inputs[0], self._train_targets
+        m = xq.shape[0]
+        fused = not self._fitted and want_var
+        if not fused:
+            self.fit()
+        try:
+            if self._train_on_engine_device(eng):
+                xq_d = xq.to(xt.device).contiguous()
+                out = torch.empty((2, m), dtype=torch.float64, device=xt.device)
+                torch.cuda.current_stream(xt.device).synchronize()  # the engine runs on its own streams
+                vptr = out[1].data_ptr() if want_var else None
+                if fused:
+                    eng.set_hyp(self.hyp_vector())
+                    self.lml = eng.fit_predict_device(
+                        xt.data_ptr(), yt.data_ptr(), xt.shape[0], xt.shape[1], xq_d.data_ptr(), m, out[0].data_ptr(), vptr, MIN_VARIANCE
+                    )
+                else:
+                    eng.predict_device(xq_d.data_ptr(), m, out[0].data_ptr(), vptr, MIN_VARIANCE)
+                mean, var = out[0].to(xq.device), (out[1].to(xq.device) if want_var else None)
+            else:
+                xq_h = xq.detach().cpu().numpy()
+                if fused:
+                    eng.set_hyp(self.hyp_vector())
+                    self.lml, mean, var = eng.fit_predict(xt.detach().cpu().numpy(), yt.detach().cpu().numpy(), xq_h, True, MIN_VARIANCE)
+                elif want_var:
+                    mean, var = eng.predict(xq_h, want_var=True, min_var=MIN_VARIANCE)
+                else:
+                    mean, var = eng.predict(xq_h, want_var=False), None
+                mean = torch.as_tensor(mean, device=xq.device)
+                var = torch.as_tensor(var, device=xq.device) if var is not None else None
+        except Exception:
+            if fused:
+                self._resident = False
+            raise
+        if fused:
+            self._resident = True
             self.jitter = eng.jitter
             self._fitted = True
-            return Posterior(mean, var, xq.device)
-        mean, var = self.engine().predict(xq_host, want_var=True, min_var=MIN_VARIANCE)
-        return Posterior(mean, var, xq.device)
+        return mean, var
+
+    def __call__(self, x) -> Posterior:
+        mean, var = self.posterior(x, want_var=True)
+        return Posterior(mean, var, mean.device)
 
     def posterior_mean(self, x) -> np.ndarray:
-        xq = torch.as_tensor(x, dtype=torch.float64)
-        self.fit()
-        return self.engine().predict(xq.detach().cpu().numpy(), want_var=False)
+        """``no_cov`` path: cross fill + GEMV against alpha, no triangular solve of the query block."""
+        mean, _ = self.posterior(x, want_var=False)
+        return mean.detach().cpu().numpy()
 
     def neg_mll(self) -> float:
         """``-mll`` with ``mll = lml / N`` - the loss of ``src/gp/training.py:29-30,39-40``."""
-        return -self.fit() / self.train_targets.shape[0]
+        return -self.fit() / self._train_targets.shape[0]
 
     def neg_mll_and_raw_grad(self):
         """``(loss, d loss / d raw)`` with ``loss = -lml / N``: the LML gradient comes from the GPU
         (``bgp_lml_grad``), the raw-parameter chain rule (sigmoid / softplus) is applied here - together
-        what ``loss.backward()`` yields in ``src/gp/training.py:41``."""
-        n = self.train_targets.shape[0]
+        what ``loss.backward()`` yields in ``src/gp/training.py:41``.  A sharded (``n_devices > 1``) model has no
+        analytic gradient pass: central differences of its LML in raw space (2 re-fits per parameter)."""
+        n = self._train_targets.shape[0]
+        if self.n_devices > 1:
+            raw = self.raw_vector()
+            g = np.zeros_like(raw)
+            for i in range(raw.size):
+                h = 1e-4 * max(1.0, abs(raw[i]))
+                rp, rm = raw.copy(), raw.copy()
+                rp[i] += h
+                rm[i] -= h
+                self.set_raw_vector(rp)
+                fp = self.neg_mll()
+                self.set_raw_vector(rm)
+                g[i] = (fp - self.neg_mll()) / (2.0 * h)
+            self.set_raw_vector(raw)
+            return self.neg_mll(), g
         lml = self.fit()
         g_hyp = self.engine().lml_grad()
         return -lml / n, -(g_hyp * self.dvalue_draw()) / n
@@ -330,7 +460,11 @@ class BatteryCellGP:
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+        if self._sharded is not None:
+            self._sharded.engine.close()
+            self._sharded = None
         self._fitted = False
+        self._resident = False
 
     def __del__(self):
         try:

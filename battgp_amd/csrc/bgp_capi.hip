@@ -1302,6 +1302,47 @@ int bgp_residuals(bgp_handle* h, int nsample, double* out2) {
   return 0;
 }
 
+int bgp_get_factor_rows(bgp_handle* h, const int64_t* rows, int nrows, double* out_host) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->fitted || !rows || !out_host || nrows < 1) return bgp_fail(h, -1, "bgp_get_factor_rows: no fit / bad arguments");
+  const int64_t N = h->N;
+  if ((rc = ensure_part(h, N))) return rc;
+  hipStream_t st = h->s_main;
+  const SlabView V = h->view();
+  for (int r = 0; r < nrows; ++r) {
+    const int64_t i = rows[r];
+    if (i < 0 || i >= N) return bgp_fail(h, -1, "bgp_get_factor_rows: row %lld outside [0, %lld)", (long long)i, (long long)N);
+    BGP_HIP(h, hipMemsetAsync(h->dpart, 0, (size_t)N * sizeof(double), st));
+    for (int64_t c0 = 0; c0 <= i;) {
+      const int64_t c1 = V.slab_end(c0, i + 1);
+      if ((rc = launch_gather_row(h, st, V.at(i, c0), V.ld(c0), c1 - c0, h->dpart + c0))) return rc;
+      c0 = c1;
+    }
+    BGP_HIP(h, hipMemcpyAsync(out_host + (size_t)r * (size_t)N, h->dpart, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+    BGP_HIP(h, hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+int bgp_get_factor_diag(bgp_handle* h, double* diag_host) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->fitted || !diag_host) return bgp_fail(h, -1, "bgp_get_factor_diag: no fit / NULL output");
+  const int64_t N = h->N, Npad = h->Npad;
+  if ((rc = ensure_part(h, Npad))) return rc;
+  hipStream_t st = h->s_main;
+  const SlabView V = h->view();
+  for (int64_t c0 = 0; c0 < Npad;) {  // the diagonal of a slab is a strided vector with stride ld + 1
+    const int64_t c1 = V.slab_end(c0, Npad);
+    if ((rc = launch_gather_row(h, st, V.at(c0, c0), V.ld(c0) + 1, c1 - c0, h->dpart + c0))) return rc;
+    c0 = c1;
+  }
+  BGP_HIP(h, hipMemcpyAsync(diag_host, h->dpart, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+  BGP_HIP(h, hipStreamSynchronize(st));
+  return 0;
+}
+
 int bgp_phase_times(const bgp_handle* h, double* out, int n) {
   if (!h || !out) return -1;
   for (int i = 0; i < n && i < BGP_T_COUNT; ++i) out[i] = h->times[i];

@@ -130,20 +130,19 @@ class ExactGPEngine:
         y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
         if x.shape[0] != y.shape[0]:
             raise ValueError("x and y disagree on N")
-        self.n, self.d = x.shape
+        n, d = x.shape
         lml, jit = C.c_double(), C.c_double()
-        rc = self._lib.bgp_fit(self._h, dptr(x), dptr(y), self.n, self.d, C.byref(lml), C.byref(jit))
+        rc = self._lib.bgp_fit(self._h, dptr(x), dptr(y), n, d, C.byref(lml), C.byref(jit))
         self._check(rc, "bgp_fit")
+        self.n, self.d = n, d  # only a successful call changes what the engine holds
         return self._after_fit(lml, jit)
 
     def fit_device(self, x_ptr: int, y_ptr: int, n: int, d: int) -> float:
         """X[n,d], y[n] already resident on this engine's GPU (e.g. ``tensor.data_ptr()``)."""
-        self.n, self.d = int(n), int(d)
         lml, jit = C.c_double(), C.c_double()
-        rc = self._lib.bgp_fit_dev(
-            self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), self.n, self.d, C.byref(lml), C.byref(jit)
-        )
+        rc = self._lib.bgp_fit_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), int(n), int(d), C.byref(lml), C.byref(jit))
         self._check(rc, "bgp_fit_dev")
+        self.n, self.d = int(n), int(d)
         return self._after_fit(lml, jit)
 
     def fit_predict(self, x: np.ndarray, y: np.ndarray, xq: np.ndarray, want_var: bool = True, min_var: float = 1e-10):
@@ -154,26 +153,27 @@ class ExactGPEngine:
             x = x.reshape(-1, 1)
         y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
         xq = np.ascontiguousarray(xq, dtype=np.float64).reshape(-1, x.shape[1])
-        self.n, self.d = x.shape
+        n, d = x.shape
         m = xq.shape[0]
         mean = np.empty(m, dtype=np.float64)
         var = np.empty(m, dtype=np.float64) if want_var else None
         lml, jit = C.c_double(), C.c_double()
         rc = self._lib.bgp_fit_predict(
-            self._h, dptr(x), dptr(y), self.n, self.d, dptr(xq), m, C.byref(lml), C.byref(jit), dptr(mean),
+            self._h, dptr(x), dptr(y), n, d, dptr(xq), m, C.byref(lml), C.byref(jit), dptr(mean),
             dptr(var) if want_var else None, float(min_var),
         )
         self._check(rc, "bgp_fit_predict")
+        self.n, self.d = n, d
         return self._after_fit(lml, jit), mean, var
 
     def fit_predict_device(self, x_ptr, y_ptr, n, d, xq_ptr, m, mean_ptr, var_ptr, min_var: float = 1e-10) -> float:
-        self.n, self.d = int(n), int(d)
         lml, jit = C.c_double(), C.c_double()
         rc = self._lib.bgp_fit_predict_dev(
-            self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), self.n, self.d, C.c_void_p(xq_ptr), int(m), C.byref(lml),
+            self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), int(n), int(d), C.c_void_p(xq_ptr), int(m), C.byref(lml),
             C.byref(jit), C.c_void_p(mean_ptr), C.c_void_p(var_ptr) if var_ptr else None, float(min_var),
         )
         self._check(rc, "bgp_fit_predict_dev")
+        self.n, self.d = int(n), int(d)
         return self._after_fit(lml, jit)
 
     def refit(self, hyp) -> float:
@@ -249,6 +249,19 @@ class ExactGPEngine:
         self._check(self._lib.bgp_get_alpha(self._h, dptr(a)), "bgp_get_alpha")
         return a
 
+    def factor_rows(self, rows) -> np.ndarray:
+        """Rows of the Cholesky factor of the last fit, ``out[r, q] = L[rows[r], q]`` (zero for q > rows[r])."""
+        rows = np.ascontiguousarray(np.asarray(rows, dtype=np.int64).reshape(-1))
+        out = np.empty((rows.size, self.n), dtype=np.float64)
+        rc = self._lib.bgp_get_factor_rows(self._h, rows.ctypes.data_as(C.POINTER(C.c_int64)), rows.size, dptr(out))
+        self._check(rc, "bgp_get_factor_rows")
+        return out
+
+    def factor_diag(self) -> np.ndarray:
+        d = np.empty(self.n, dtype=np.float64)
+        self._check(self._lib.bgp_get_factor_diag(self._h, dptr(d)), "bgp_get_factor_diag")
+        return d
+
     def residuals(self, nsample: int = 256):
         out = np.zeros(2, dtype=np.float64)
         self._check(self._lib.bgp_residuals(self._h, int(nsample), dptr(out)), "bgp_residuals")
@@ -277,6 +290,18 @@ class ExactGPEngine:
             self._h, C.c_void_p(c_ptr), ldc, C.c_void_p(a_ptr), lda, C.c_void_p(b_ptr), ldb, m, n, k, int(lower)
         )
         self._check(rc, "bgp_gemm_nt_sub_dev")
+
+    def fill_block_device(self, x_ptr, n, d, row0, col0, nrows, ncols, out_ptr, ld, extra_diag=0.0) -> None:
+        """Block [row0, row0+nrows) x [col0, col0+ncols) of Sigma = K(X, X) + (noise + extra_diag) I into a
+        column-major device buffer (asynchronous on the engine's stream: call :meth:`sync`)."""
+        rc = self._lib.bgp_fill_block_dev(
+            self._h, C.c_void_p(x_ptr), int(n), int(d), int(row0), int(col0), int(nrows), int(ncols), C.c_void_p(out_ptr), int(ld),
+            float(extra_diag),
+        )
+        self._check(rc, "bgp_fill_block_dev")
+
+    def sync(self) -> None:
+        self._check(self._lib.bgp_sync(self._h), "bgp_sync")
 
     def fill_device(self, x1_ptr, n1, x2_ptr, n2, d, out_ptr, ld, lower=0, diag_add=0.0) -> None:
         rc = self._lib.bgp_fill_dev(

@@ -230,6 +230,13 @@ class ShardedExactGP:
         self.lml = None
         self.jitter = 0.0
 
+    def set_hyp(self, hyp) -> None:
+        """New hyper-parameters for the next :meth:`fit` (every rank must pass the same vector)."""
+        self.hyp = np.asarray(hyp, dtype=np.float64).copy()
+        eng = getattr(self, "engine", None)
+        if eng is not None:
+            eng.set_hyp(self.hyp)
+
     # ---- collectives (torch.distributed on backend buffers; numpy buffers are wrapped in place) ------
     @staticmethod
     def _t(buf):

@@ -193,6 +193,16 @@ int bgp_get_alpha(bgp_handle* h, double* alpha_host);
  *   out[1] = max over `nsample` sampled entries of |(L L^T)_ij - Sigma_ij| / Sigma_ii-scale */
 int bgp_residuals(bgp_handle* h, int nsample, double* out2);
 
+/* Rows of the Cholesky factor of the last fit, for checks that must not trust the engine's own covariance
+ * function: out_host[r * N + q] = L[rows[r], q] for q <= rows[r] (zero beyond), r < nrows, rows[r] < N.
+ * The test side forms (L L^T)_ij = <row i, row j> and compares it with Sigma_ij evaluated by the CPU oracle.
+ * Works for both layouts (full square / column slabs). */
+int bgp_get_factor_rows(bgp_handle* h, const int64_t* rows, int nrows, double* out_host);
+
+/* diag_host[i] = L_ii, i < N, of the last fit (log det Sigma = 2 sum log L_ii: lets a caller re-derive the LML
+ * on the host from alpha and this vector). */
+int bgp_get_factor_diag(bgp_handle* h, double* diag_host);
+
 /* Per-phase timings of the most recent calls, see BGP_T_* (n <= BGP_T_COUNT values). */
 int bgp_phase_times(const bgp_handle* h, double* out, int n);
 

@@ -82,7 +82,9 @@ class OracleGP:
     # -- fit -----------------------------------------------------------------
     def fit(self) -> "OracleGP":
         n = self.x.shape[0]
-        sigma = K.kernel_matrix(self.kernel_id, self.hyp, self.x)
+        # large N: same entries, evaluated block-wise on the host cores (bit-identical, see kernels.py)
+        fill = K.kernel_matrix if n <= 2048 else K.kernel_matrix_blocked
+        sigma = fill(self.kernel_id, self.hyp, self.x)
         sigma[np.diag_indices(n)] += K.noise(self.hyp)
         self.L, self.jitter = psd_safe_cholesky(sigma)
         # alpha = Sigma^-1 y  (mean cache of DefaultPredictionStrategy)

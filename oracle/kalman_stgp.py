@@ -79,13 +79,22 @@ class KalmanSTGP:
         hs = h[:, self.nt :]
         return ktt + h @ p @ h.T - hs @ self.kbb @ hs.T
 
-    def update(self, xs: np.ndarray, y: np.ndarray) -> None:
+    def update(self, xs: np.ndarray, y: np.ndarray) -> float:
+        """Measurement update; returns the innovation log-likelihood
+        ``log N(y | H z, C + sigma^2 I)`` of this batch.  Summed over the filter run it is the joint
+        ``log p(y_1..n)`` - the exact GP's log-marginal likelihood when the equivalence conditions of
+        ``tests/gp/test_spatiotemporal_gp.py:218-222`` hold - which pins the LML independently of any
+        Cholesky of the full covariance."""
         h, ktt = self._output_matrix(xs)
         c = self._covariance(h, ktt, self.P)
         v = np.asarray(y, dtype=np.float64).reshape(-1, 1) - h @ self.z
-        gain = self.P @ h.T @ np.linalg.inv(c + np.eye(xs.shape[0]) * self.noise_var)
+        s = c + np.eye(xs.shape[0]) * self.noise_var
+        s_inv = np.linalg.inv(s)
+        gain = self.P @ h.T @ s_inv
         self.z = self.z + gain @ v
         self.P = self.P - gain @ h @ self.P
+        _, logdet = np.linalg.slogdet(s)
+        return float(-0.5 * (v.T @ s_inv @ v).item() - 0.5 * logdet - 0.5 * xs.shape[0] * np.log(2.0 * np.pi))
 
     def predict(self, xq: np.ndarray):
         h, kqq = self._output_matrix(xq)

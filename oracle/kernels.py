@@ -96,6 +96,38 @@ def kernel_matrix(
     raise ValueError(f"unknown kernel id {kernel_id}")
 
 
+def kernel_matrix_blocked(
+    kernel_id: int, hyp: np.ndarray, x: np.ndarray, block: int = 1024, threads: int | None = None
+) -> np.ndarray:
+    """``kernel_matrix(kernel_id, hyp, x)`` for large N: the lower-triangle blocks are evaluated by
+    :func:`kernel_matrix` on a thread pool (numpy ufuncs release the GIL) and mirrored.  Every entry goes through
+    exactly the arithmetic of :func:`kernel_matrix` (all operations are elementwise), so the result is
+    bit-identical to the one-shot evaluation - it only keeps the temporaries small and uses the host cores."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1)
+    n = x.shape[0]
+    out = np.empty((n, n), dtype=np.float64)
+    starts = list(range(0, n, block))
+    jobs = [(i0, j0) for i0 in starts for j0 in starts if j0 <= i0]
+
+    def run(job):
+        i0, j0 = job
+        i1, j1 = min(i0 + block, n), min(j0 + block, n)
+        blk = kernel_matrix(kernel_id, hyp, x[i0:i1], x[j0:j1])
+        out[i0:i1, j0:j1] = blk
+        if i0 != j0:
+            out[j0:j1, i0:i1] = blk.T
+
+    workers = threads or min(32, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        list(pool.map(run, jobs))
+    return out
+
+
 def kernel_diag(kernel_id: int, hyp: np.ndarray, x: np.ndarray) -> np.ndarray:
     """``diag K(x, x)`` (noise-free).  K0 follows the ``diag=True`` branch of
     ``src/gp/wiener_kernel.py:15-16`` (``min = t`` => ``t^3/3``)."""

@@ -15,6 +15,19 @@ Everything else on the hot path needs gpytorch, which is not installed here, so
 vectors for the HIP parity tests; the oracle itself is pinned by the known-answer
 tests in ``tests/test_oracle.py`` and by ``stgp_egp.npz``).
 
+``lml_pins.npz`` pins the LOG-MARGINAL LIKELIHOOD independently of the oracle and of the HIP engine:
+
+* ``torch.distributions.MultivariateNormal(0, Sigma).log_prob(y)`` - what the reference evaluates at
+  ``src/gp/training.py:27-30,39-40`` through gpytorch's ``MultivariateNormal`` / ``ExactMarginalLogLikelihood``
+  (``mll = log_prob / N``) - with ``Sigma`` assembled HERE in torch the way the reference's modules assemble
+  it: the integrated-Wiener term following ``src/gp/wiener_kernel.py:10-32`` (``covar_dist`` distance, the
+  column loop of ``torch.minimum``), the RBF term by gpytorch's mean-centred quadratic-expansion squared
+  distance with ``clamp_min(0)`` and a zeroed self-diagonal, ``div(-2).exp()``, the two ``ScaleKernel``
+  factors and ``+ sigma^2 I`` (``src/batt_models/cell_gp.py:27-36``).  Different arithmetic (quadratic
+  expansion vs direct differences) and a different LAPACK (torch/MKL vs scipy/OpenBLAS) than the oracle.
+* the Kalman filter's summed innovation log-likelihood for the ``stgp_egp`` case, driven by the reference's
+  own ``WienerTemporalKernel`` ``(A, Q)`` - no N x N factorisation at all.
+
 Only data (inputs and expected outputs) is written; no reference source travels.
 """
 
@@ -68,10 +81,12 @@ def make_stgp_egp(path: str) -> None:
 
     rbf_hyp = np.array([0.0, s_r, ell, ell, ell])
     kf = KalmanSTGP(s_base, rbf_hyp, noise, ref_kernel.get_kalman_matrices)
-    means, varis = [], []
+    means, varis, lmls = [], [], []
+    ll = 0.0
     for i in range(len(tt)):
         kf.time_step(tt[i] - kf.t)
-        kf.update(st[[i], :], yt[[i]])
+        ll += kf.update(st[[i], :], yt[[i]])
+        lmls.append(ll)  # joint log p(y_1..y_{i+1}) = LML of the exact GP on the first i+1 points
         m, v = kf.predict(sq)
         means.append(m)
         varis.append(v)
@@ -85,6 +100,7 @@ def make_stgp_egp(path: str) -> None:
         hyp=np.array([noise, s_w, s_r, ell, ell, ell]),
         kalman_mean=np.array(means),
         kalman_var=np.array(varis),
+        kalman_lml=np.array(lmls),
     )
     # sanity: the oracle agrees at the reference's tolerance
     hyp = np.array([noise, s_w, s_r, ell, ell, ell])
@@ -94,7 +110,103 @@ def make_stgp_egp(path: str) -> None:
         m, v = gp.predict(xq)
         assert np.linalg.norm(m - means[i]) < 1e-6 * np.linalg.norm(m)
         assert np.linalg.norm(v - varis[i]) < 1e-6 * np.linalg.norm(v)
+        assert abs(gp.lml - lmls[i]) < 1e-6 * abs(lmls[i]), (i, gp.lml, lmls[i])
     print("stgp_egp.npz ok")
+
+
+# ---- LML pins: torch.distributions on a covariance assembled the gpytorch way ------------------------
+def _gpytorch_sq_dist(x1, x2, x1_eq_x2):
+    """gpytorch ``Kernel.covar_dist(square_dist=True)``: mean-centred quadratic expansion, self-diagonal
+    zeroed, clamped at 0 (restated from the gpytorch >= 1.11 sources the reference depends on)."""
+    import torch
+
+    adj = x1.mean(-2, keepdim=True)
+    x1 = x1 - adj
+    x2 = x2 - adj
+    n1 = x1.pow(2).sum(-1, keepdim=True)
+    n2 = x2.pow(2).sum(-1, keepdim=True)
+    a = torch.cat([-2.0 * x1, n1, torch.ones_like(n1)], dim=-1)
+    b = torch.cat([x2, torch.ones_like(n2), n2], dim=-1)
+    res = a.matmul(b.transpose(-2, -1))
+    if x1_eq_x2:
+        res.diagonal(dim1=-2, dim2=-1).fill_(0)
+    return res.clamp_min_(0)
+
+
+def _torch_kernel(kernel_id, hyp, x1, x2=None):
+    """Noise-free K(x1, x2) in torch, assembled like the reference's kernel modules (x2=None: x1 with itself)."""
+    import torch
+
+    same = x2 is None
+    x1 = torch.as_tensor(x1, dtype=torch.float64)
+    x2 = x1 if same else torch.as_tensor(x2, dtype=torch.float64)
+    if kernel_id == K.KERNEL_BATTGP:
+        t1, t2 = x1[:, :1], x2[:, :1]
+        # WienerKernel.forward (src/gp/wiener_kernel.py:10-32): distance = covar_dist, minval by a column loop
+        distance = _gpytorch_sq_dist(t1, t2, same).clamp_min_(1e-30).sqrt_()
+        minval = distance.clone()
+        for c in range(x2.shape[0]):
+            minval[:, c] = torch.minimum(t1, t2[c]).reshape((-1,))
+        wiener = torch.pow(minval, 3) / 3 + distance * torch.pow(minval, 2) / 2
+        ls = torch.as_tensor(hyp[3:], dtype=torch.float64).reshape(1, -1)
+        rbf = _gpytorch_sq_dist(x1[:, 1:].div(ls), x2[:, 1:].div(ls), same).div(-2).exp()
+        return hyp[1] * wiener + hyp[2] * rbf
+    if kernel_id == K.KERNEL_SCALED_RBF:
+        return hyp[1] * _gpytorch_sq_dist(x1.div(float(hyp[2])), x2.div(float(hyp[2])), same).div(-2).exp()
+    raise ValueError(kernel_id)
+
+
+def _torch_sigma(kernel_id, hyp, x):
+    import torch
+
+    return _torch_kernel(kernel_id, hyp, x) + float(hyp[0]) * torch.eye(len(x), dtype=torch.float64)
+
+
+def make_lml_pins(path: str) -> None:
+    import torch
+
+    out = {}
+    for n in (10, 64, 512):
+        x, y = synthetic.make_cell_data(n, seed=7000 + n)
+        xs = synthetic.standardise(x)
+        cases = {
+            "k0prod": (K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y),
+            # the hyper-parameters of the reference's own exact-GP test (test_spatiotemporal_gp.py:226-230)
+            "k0test": (K.KERNEL_BATTGP, np.array([0.1, 10.0, 3.0, 2.0, 2.0, 2.0]), np.column_stack((x[:, 0] / 120.0, xs[:, 1:])), (y - y.mean()) * 1e3),
+            "k1": (K.KERNEL_SCALED_RBF, np.array([3.0, 3.0, 2.0]), xs, (y - y.mean()) * 1e3),
+        }
+        for name, (kid, hyp, xx, yy) in cases.items():
+            sigma = _torch_sigma(kid, hyp, xx)
+            mvn = torch.distributions.MultivariateNormal(torch.zeros(n, dtype=torch.float64), covariance_matrix=sigma)
+            lml = float(mvn.log_prob(torch.as_tensor(yy, dtype=torch.float64)))
+            # posterior of the latent f by an LU solve (torch.linalg.solve - no Cholesky anywhere):
+            # mean = K_*X Sigma^-1 y, var = diag(K_**) - diag(K_*X Sigma^-1 K_X*)   (battcellgp_full.py:171-180)
+            xq = xx[:: max(1, n // 16)] * 0.999 + 0.001 * xx.mean(axis=0)
+            kxs = _torch_kernel(kid, hyp, xx, xq)
+            sol = torch.linalg.solve(sigma, torch.cat([torch.as_tensor(yy, dtype=torch.float64).reshape(-1, 1), kxs], dim=1))
+            mean_t = (kxs.T @ sol[:, 0]).numpy()
+            # prior variance at the queries: the diag=True branch of the kernels (wiener_kernel.py:15-16)
+            kss = torch.as_tensor(K.kernel_diag(kid, hyp, xq))
+            var_t = (kss - (kxs * sol[:, 1:]).sum(dim=0)).numpy()
+            gp = OracleGP(kid, hyp, xx, yy).fit()
+            m_o, v_o = gp.predict(xq, clamp=False)
+            assert gp.jitter == 0.0
+            assert abs(gp.lml - lml) < 1e-6 * abs(lml), (name, n, gp.lml, lml)
+            assert np.linalg.norm(m_o - mean_t) < 1e-6 * np.linalg.norm(mean_t), (name, n)
+            assert np.max(np.abs(v_o - var_t)) < 1e-6 * np.max(np.abs(var_t)) + 1e-9 * float(hyp[1] if kid else hyp[2]), (name, n)
+            print(f"  pin {name} n={n}: lml torch {lml:.12g} oracle {gp.lml:.12g} rel {abs(gp.lml - lml) / abs(lml):.1e}; "
+                  f"mean rel {np.linalg.norm(m_o - mean_t) / np.linalg.norm(mean_t):.1e}, var abs {np.max(np.abs(v_o - var_t)):.1e}")
+            p = f"{name}_n{n}_"
+            out[p + "kernel_id"] = np.int64(kid)
+            out[p + "hyp"] = np.asarray(hyp, dtype=np.float64)
+            out[p + "x"] = xx
+            out[p + "y"] = yy
+            out[p + "lml_torch_mvn"] = np.float64(lml)
+            out[p + "xq"] = xq
+            out[p + "mean_torch_solve"] = mean_t
+            out[p + "var_torch_solve"] = var_t
+    np.savez_compressed(path, **out)
+    print("lml_pins.npz ok")
 
 
 def _case(kernel_id, hyp, x, y, xq):
@@ -174,5 +286,6 @@ def make_n2048(path: str) -> None:
 
 if __name__ == "__main__":
     make_stgp_egp(os.path.join(HERE, "stgp_egp.npz"))
+    make_lml_pins(os.path.join(HERE, "lml_pins.npz"))
     make_oracle_cases(os.path.join(HERE, "oracle_cases.npz"))
     make_n2048(os.path.join(HERE, "oracle_n2048.json"))

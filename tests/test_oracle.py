@@ -79,6 +79,39 @@ def test_stgp_egp_golden(golden_dir):
         assert np.linalg.norm(v - g["kalman_var"][i]) < 1e-6 * np.linalg.norm(v)
 
 
+def test_lml_pinned_by_kalman_innovation_likelihood(golden_dir):
+    """LML of the exact GP == the Kalman filter's summed innovation log-likelihood (joint density of the
+    observations), the filter being driven by the reference's own WienerTemporalKernel (A, Q)
+    (tests/golden/make_golden.py).  No N x N factorisation on the pinning side."""
+    g = np.load(os.path.join(golden_dir, "stgp_egp.npz"))
+    xt, yt, hyp = g["xt"], g["yt"], g["hyp"]
+    for i, want in enumerate(g["kalman_lml"]):
+        gp = OracleGP(K.KERNEL_BATTGP, hyp, xt[: i + 1], yt[: i + 1]).fit()
+        assert abs(gp.lml - want) < 1e-6 * abs(want), (i, gp.lml, want)
+
+
+LML_PIN_CASES = [(name, n) for name in ("k0prod", "k0test", "k1") for n in (10, 64, 512)]
+
+
+@pytest.mark.parametrize("name,n", LML_PIN_CASES)
+def test_lml_and_posterior_pinned_by_torch(golden_dir, name, n):
+    """LML == torch.distributions.MultivariateNormal(0, Sigma).log_prob(y) - what src/gp/training.py:27-30,39-40
+    evaluates through gpytorch - and the posterior == an LU solve (torch.linalg.solve), with Sigma assembled in
+    torch the way the reference's kernel modules do (committed values: tests/golden/lml_pins.npz); north-star
+    tolerance 1e-6 relative."""
+    g = np.load(os.path.join(golden_dir, "lml_pins.npz"))
+    p = f"{name}_n{n}_"
+    kid, hyp = int(g[p + "kernel_id"]), g[p + "hyp"]
+    gp = OracleGP(kid, hyp, g[p + "x"], g[p + "y"]).fit()
+    want = float(g[p + "lml_torch_mvn"])
+    assert gp.jitter == 0.0
+    assert abs(gp.lml - want) < 1e-6 * abs(want), (gp.lml, want)
+    m, v = gp.predict(g[p + "xq"], clamp=False)
+    assert np.linalg.norm(m - g[p + "mean_torch_solve"]) < 1e-6 * np.linalg.norm(m)
+    prior = float(hyp[2] if kid == K.KERNEL_BATTGP else hyp[1])
+    assert np.max(np.abs(v - g[p + "var_torch_solve"])) < 1e-6 * np.max(np.abs(v)) + 1e-9 * prior
+
+
 def test_oracle_regression_vectors(golden_dir):
     g = np.load(os.path.join(golden_dir, "oracle_cases.npz"))
     for kname in ("k0", "k1", "k2", "k3"):
