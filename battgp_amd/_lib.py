@@ -77,10 +77,19 @@ SIGNATURES = {
         C.c_int,
         [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int],
     ),
-    "bgp_update_panels_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_int64, C.c_int]),
+    "bgp_update_panels_dev": (C.c_int, [handle_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "bgp_factor_pack_panel_async_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    ),
+    "bgp_flag_reset_dev": (C.c_int, [handle_p]),
+    "bgp_flag_merge_dev": (C.c_int, [handle_p, C.c_void_p]),
+    "bgp_flag_read": (C.c_int, [handle_p, c_int_p]),
+    "bgp_get_stream": (C.c_void_p, [handle_p, C.c_int]),
     "bgp_diag_logsum_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
     "bgp_rowdot_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "bgp_var_finish_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double, C.c_void_p]),
+    "bgp_debug_clock_samples_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int, C.c_int]),
     "bgp_sync": (C.c_int, [handle_p]),
 }
 

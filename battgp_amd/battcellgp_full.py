@@ -100,6 +100,10 @@ def hyperparameter_table(params: dict, lml=None) -> pd.DataFrame:
     return table
 
 
+def _host_vector(t: torch.Tensor) -> np.ndarray:
+    return np.asarray(t.cpu(), dtype=np.float64).ravel()
+
+
 def _torch_device(device) -> torch.device:
     """``device=`` as the callers pass it: ``None``, an index (``gp_runner.py:162-171``), a string or a
     ``torch.device``.  There is no CPU engine: "not given" means GPU 0 (the reference's default is the CPU), and an
@@ -114,9 +118,9 @@ def _torch_device(device) -> torch.device:
 class BatteryCellGP_Full:
     """``IBatteryCellGP`` for one cell (or the pack): exact GP with the Wiener + ARD-RBF kernel on one MI355X."""
 
-    def __init__(self, x: np.ndarray, y: np.ndarray, cellnr: Optional[int] = None, **kwargs):
+    def __init__(self, x, y, cellnr=None, **kwargs):
         self._cellnr = cellnr
-        self.params: dict[str, Any] = self.get_default_parameters()
+        self.params = BatteryCellGP_Full.get_default_parameters()
         for name in kwargs:
             if name not in self.params and name not in _NOT_RECORDED:
                 raise ValueError(f"unknown keyword parameter '{name}'")
@@ -144,8 +148,7 @@ class BatteryCellGP_Full:
         for spec in _HYPERS:  # range first: the value is stored through the constraint's transform
             setattr(self.model, spec.constraint_attr, self.params[spec.range_key])
             setattr(self.model, spec.key, self.params[spec.key])
-        self.model.eval()
-        self.model.likelihood.eval()
+        # (a fresh BatteryCellGP and its likelihood are already in eval mode)
 
     # -- identity / parameters ------------------------------------------------------------------------------
     @property
@@ -153,21 +156,21 @@ class BatteryCellGP_Full:
         return self._cellnr
 
     @staticmethod
-    def get_default_parameters() -> dict[str, Any]:
+    def get_default_parameters():
         out: dict[str, Any] = {spec.key: spec.default for spec in _HYPERS}
         out.update({spec.range_key: spec.default_range for spec in _HYPERS})
         out.update({key: default for key, (default, _) in _SETTINGS.items()})
         return out
 
-    def get_parameters(self) -> dict[str, Any]:
-        return copy.deepcopy(self.params)
+    def get_parameters(self):
+        return {key: copy.deepcopy(value) for key, value in self.params.items()}
 
-    def save_hyperparameters(self, path: str) -> None:
+    def save_hyperparameters(self, path):
         table = hyperparameter_table(self.params, lml=self.marginallikelihood)
         table.to_csv(os.path.join(path, f"{self._cellnr}hyperparams.csv"))
 
     # -- training -------------------------------------------------------------------------------------------
-    def train_hyperparameters(self, messages: bool = True) -> np.ndarray:
+    def train_hyperparameters(self, messages=True):
         """Optimise the hyper-parameters with the algorithm named in ``cfg.HYPER_OPT_PARAMS`` (each iteration = one
         resident re-fit + one gradient pass on the GPU), write the optimum back into ``params`` and remember the
         final loss (``-mll * N``) as ``marginallikelihood``."""
@@ -180,7 +183,7 @@ class BatteryCellGP_Full:
             self.model, self.model.train_inputs[0], targets, loss_scale=len(targets), messages=messages, **trainer_args
         )
         for spec in _HYPERS:
-            learned = getattr(self.model, spec.key).detach().cpu().numpy().ravel()
+            learned = _host_vector(getattr(self.model, spec.key))
             if len(spec.labels) > 1:
                 self.params[spec.key] = tuple(learned)
             else:
@@ -189,14 +192,14 @@ class BatteryCellGP_Full:
         return history
 
     # -- prediction -----------------------------------------------------------------------------------------
-    def predict(self, x: np.ndarray, full_cov: bool = False, no_cov: bool = False):
+    def predict(self, x, full_cov=False, no_cov=False):
         """Posterior of the latent resistance at ``x [M, 4]``: ``mean`` alone (``no_cov``), ``(mean, var [M])``, or
         ``(mean, [M, M])`` with ``full_cov`` - which, like the reference, carries only the marginal variances on
         the diagonal of an otherwise-NaN matrix."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         if no_cov:
             return self.model.posterior_mean(x)  # cross fill + GEMV against alpha, no triangular solve
-        mean, var = (t.detach().cpu().numpy().reshape(-1) for t in self.model.posterior(x))
+        mean, var = map(_host_vector, self.model.posterior(x))
         if not full_cov:
             return mean, var
         square = np.full((len(var), len(var)), np.nan, dtype=np.float64)
@@ -213,9 +216,9 @@ class BatteryCellGP_Full:
         tag = f"acausal_{_series_tag(self._cellnr)}"
         return pd.DataFrame({"t": t, f"r0_{tag}": r0, f"r0var_{tag}": r0_var})
 
-    def get_training_data(self) -> tuple[np.ndarray, np.ndarray]:
-        x, y = self.model.train_inputs[0], self.model.train_targets
-        return x.detach().cpu().numpy(), y.detach().cpu().numpy().reshape(-1)
+    def get_training_data(self):
+        """``(X [N, 4], y [N])`` as numpy arrays."""
+        return np.asarray(self.model.train_inputs[0].cpu()), _host_vector(self.model.train_targets)
 
     # -- lifetime -------------------------------------------------------------------------------------------
     def __delattr__(self, name):
@@ -228,11 +231,11 @@ class BatteryCellGP_Full:
         super().__delattr__(name)
 
 
-def build_cellmodel_full(cellnr: int, batt_data, max_training_data: int, max_age: Optional[int] = None, device=None, **kwargs):
+def build_cellmodel_full(cellnr, batt_data, max_training_data, max_age=None, device=None, **kwargs):
     """Factory used by ``BattGP_Full`` (``src/batt_models/battgp_full.py:41-60``): ``batt_data`` is anything with the
     reference's ``generateTrainingData(cellnr, max_training_data, max_age) -> (X[N, 4], y[N])``."""
-    x, y = batt_data.generateTrainingData(cellnr, max_training_data, max_age)
-    return BatteryCellGP_Full(x, y, cellnr, device=device, **kwargs)
+    inputs, resistance = batt_data.generateTrainingData(cellnr, max_training_data, max_age)
+    return BatteryCellGP_Full(inputs, resistance, cellnr=cellnr, device=device, **kwargs)
 
 
 def predict_cells_concurrently(cellmodels, op, t: np.ndarray) -> list[pd.DataFrame]:

@@ -284,6 +284,10 @@ class BatteryCellGP:
         return [self._c_noise, self._c_sw, self._c_sr, self._c_ls]
 
     def raw_vector(self) -> np.ndarray:
+        # after set_raw_vector() the raw values themselves are kept: value -> raw is lossy once a parameter has
+        # saturated at a bound of its interval (sigmoid(raw) rounds to 0 or 1), and gpytorch stores the raw tensors
+        if getattr(self, "_raw", None) is not None:
+            return self._raw.copy()
         return np.concatenate(
             (
                 np.atleast_1d(self._c_noise.inverse_transform(self._noise)),
@@ -300,6 +304,7 @@ class BatteryCellGP:
         self._outputscale_rbf = float(self._c_sr.transform(raw[2]))
         self._lengthscale_rbf = np.atleast_1d(self._c_ls.transform(raw[3:])).astype(np.float64)
         self._invalidate()
+        self._raw = raw.copy()
 
     def dvalue_draw(self) -> np.ndarray:
         raw = self.raw_vector()
@@ -315,6 +320,7 @@ class BatteryCellGP:
     # -- engine --------------------------------------------------------------------------------
     def _invalidate(self):
         self._fitted = False
+        self._raw = None  # a value or constraint was set directly: raw parameters follow from the values again
 
     def engine(self) -> ExactGPEngine:
         if self._engine is None:
@@ -461,7 +467,7 @@ class BatteryCellGP:
             self._engine.close()
             self._engine = None
         if self._sharded is not None:
-            self._sharded.engine.close()
+            self._sharded.close()
             self._sharded = None
         self._fitted = False
         self._resident = False
@@ -488,6 +494,7 @@ class BatteryCellGP:
     @noise_variance_constraint.setter
     def noise_variance_constraint(self, value):
         self._c_noise = constraint_from_range(value)
+        self._raw = None
 
     @property
     def outputscale_wiener(self):
@@ -505,6 +512,7 @@ class BatteryCellGP:
     @outputscale_wiener_constraint.setter
     def outputscale_wiener_constraint(self, value):
         self._c_sw = constraint_from_range(value)
+        self._raw = None
 
     @property
     def outputscale_rbf(self):
@@ -522,6 +530,7 @@ class BatteryCellGP:
     @outputscale_rbf_constraint.setter
     def outputscale_rbf_constraint(self, value):
         self._c_sr = constraint_from_range(value)
+        self._raw = None
 
     @property
     def lengthscale_rbf(self):

@@ -547,6 +547,7 @@ void free_problem(bgp_handle* h) {
   h->D = 0;
   h->fitted = false;
   h->has_data = false;
+  h->t_sorted = false;
 }
 
 // Layout of the factor: full square when it fits (one launch per trailing update), column slabs
@@ -644,6 +645,8 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mri
     FillParams p;
     int rc = make_fill_params(h, h->D, jitter, &p);
     if (rc) return rc;
+    FillParams pt = p;  // the training fill may use min(t_i, t_j) = t_j below the diagonal of a time-sorted X
+    pt.t_sorted = h->t_sorted ? 1 : 0;
     {
       PhaseTimer t(h, st, BGP_T_FILL, true);
       // per column slab: the lower trapezoid from the slab's diagonal down + its part of the y^T block
@@ -652,7 +655,7 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mri
         const int64_t c1 = V.slab_end(c0, Npad);
         const int64_t nv = N > c0 ? N - c0 : 0;
         const double* xs = h->dX + c0 * h->D;
-        rc = launch_fill(h, st, p, xs, Npad - c0, xs, c1 - c0, V.at(c0, c0), V.ld(c0), 1, 1, nv, nv);
+        rc = launch_fill(h, st, pt, xs, Npad - c0, xs, c1 - c0, V.at(c0, c0), V.ld(c0), 1, 1, nv, nv);
         if (rc) return rc;
         if ((rc = launch_aug_rows(h, st, h->dy + c0, nv, V.at(Npad, c0), V.ld(c0), c1 - c0, BGP_AUG))) return rc;
         c0 = c1;
@@ -905,6 +908,7 @@ void reset_logical(bgp_handle* h) {
   h->slab_req = fresh.slab_req;
   h->fitted = false;
   h->has_data = false;
+  h->t_sorted = false;
   h->alpha_ready = false;
   h->jitter_used = 0.0;
   h->lml = 0.0;
@@ -1089,6 +1093,14 @@ int bgp_get_layout(const bgp_handle* h, int64_t* slab_width_out, int64_t* factor
   return 0;
 }
 
+// is column 0 of the resident X ascending?  (answer lands in hinfo[1] with the upload's own synchronisation)
+static int note_time_order(bgp_handle* h) {
+  int rc = launch_check_sorted(h, h->s_main, h->dX, h->N, h->D, h->dinfo + 1);
+  if (rc) return rc;
+  BGP_HIP(h, hipMemcpyAsync(h->hinfo + 1, h->dinfo + 1, sizeof(int), hipMemcpyDeviceToHost, h->s_main));
+  return 0;
+}
+
 static int fit_common(bgp_handle* h, const double* X, const double* y, int64_t N, int D, bool on_device,
                       double* lml_out, double* jitter_out) {
   int rc = check_handle(h);
@@ -1102,8 +1114,10 @@ static int fit_common(bgp_handle* h, const double* X, const double* y, int64_t N
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     BGP_HIP(h, hipMemcpyAsync(h->dX, X, (size_t)N * D * sizeof(double), kind, h->s_main));
     BGP_HIP(h, hipMemcpyAsync(h->dy, y, (size_t)N * sizeof(double), kind, h->s_main));
+    if ((rc = note_time_order(h))) return rc;
     if ((rc = t.stop())) return rc;
   }
+  h->t_sorted = h->hinfo[1] == 0;
   h->has_data = true;
   return fit_resident(h, lml_out, jitter_out);
 }
@@ -1144,8 +1158,10 @@ static int fit_predict_common(bgp_handle* h, const double* X, const double* y, i
     BGP_HIP(h, hipMemcpyAsync(h->dX, X, (size_t)N * D * sizeof(double), kin, h->s_main));
     BGP_HIP(h, hipMemcpyAsync(h->dy, y, (size_t)N * sizeof(double), kin, h->s_main));
     BGP_HIP(h, hipMemcpyAsync(h->dXq, Xq, (size_t)M * D * sizeof(double), kin, h->s_main));
+    if ((rc = note_time_order(h))) return rc;
     if ((rc = t.stop())) return rc;
   }
+  h->t_sorted = h->hinfo[1] == 0;
   h->has_data = true;
   if ((rc = fit_resident(h, lml_out, jitter_out, M))) return rc;
   if ((rc = ride_posterior(h, M, var != nullptr, min_var))) return rc;
@@ -1477,8 +1493,72 @@ int bgp_gemm_nt_sub_async_dev(bgp_handle* h, double* C_dev, int64_t ldc, const d
   return launch_gemm_nt(h, h->s_main, 0, 128, C_dev, ldc, A_dev, lda, B_dev, ldb, m, n, k, lower);
 }
 
-int bgp_update_panels_dev(bgp_handle* h, double* store_dev, int64_t ld, const int64_t* desc, int count,
-                          const double* P_dev, int64_t ldp, int k) {
+int bgp_factor_pack_panel_async_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t nrows, int nbk, double* inv_dev,
+                                    double* pack_dev, int64_t gofs, double* flag_slot_dev) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const int64_t NB = h->nb_outer;
+  if (!panel_dev || !inv_dev || !pack_dev || nbk < 64 || (nbk % 64) != 0 || nbk > NB || nrows < nbk || (nrows & 1) ||
+      (ld & 1) || gofs < 0)
+    return bgp_fail(h, -1, "bgp_factor_pack_panel_async_dev: bad arguments (nrows=%lld nbk=%d ld=%lld nb_outer=%lld)",
+                    (long long)nrows, nbk, (long long)ld, (long long)NB);
+  if ((rc = ensure_panel_ws(h, 0, NB, 0))) return rc;
+  hipStream_t st = h->s_main;
+  const int64_t ldd = 2 * NB, below = nrows - nbk;
+  // tile inverses are indexed by the panel-local tile (inv_dev belongs to this panel); the failing minor globally
+  if ((rc = launch_diag_in(h, st, panel_dev, ld, h->dD, ldd, nbk))) return rc;
+  for (int64_t j = 0; j < nbk; j += BGP_IB) {  // factor_panel with a global report offset but panel-local inverses
+    double* inv_j = inv_dev + (j / BGP_IB) * (BGP_IB * BGP_IB);
+    if ((rc = launch_potrf_tile(h, st, h->dD + j + j * ldd, ldd, inv_j, h->dinfo, (int)(j + gofs), 64))) return rc;
+    const int64_t rows_below = 2 * (int64_t)nbk - (j + BGP_IB);
+    double* A21 = h->dD + (j + BGP_IB) + j * ldd;
+    if ((rc = launch_gemm_nt(h, st, 1, 64, A21, ldd, A21, ldd, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0, h->dinfo))) return rc;
+    const int64_t ncols = nbk - (j + BGP_IB);
+    if (ncols > 0 && (rc = launch_gemm_nt(h, st, 0, 128, h->dD + (j + BGP_IB) + (j + BGP_IB) * ldd, ldd, A21, ldd, A21, ldd,
+                                          rows_below, ncols, BGP_IB, 1, h->dinfo)))
+      return rc;
+  }
+  if ((rc = launch_diag_out(h, st, h->dD, ldd, panel_dev, ld, h->dLinv, NB, nbk))) return rc;
+  if ((rc = launch_copy_panel(h, st, panel_dev, ld, pack_dev, nrows, nbk, nbk))) return rc;
+  if (below > 0) {
+    rc = launch_gemm_nt(h, st, 1, 64, pack_dev + nbk, nrows, panel_dev + nbk, ld, h->dLinv, NB, below, nbk, nbk, 0, h->dinfo, 1);
+    if (rc) return rc;
+    if ((rc = launch_copy_panel(h, st, pack_dev + nbk, nrows, panel_dev + nbk, ld, below, nbk))) return rc;
+  }
+  if (flag_slot_dev && (rc = launch_flag_store(h, st, h->dinfo, flag_slot_dev))) return rc;
+  return 0;
+}
+
+int bgp_flag_reset_dev(bgp_handle* h) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  BGP_HIP(h, hipMemsetAsync(h->dinfo, 0, sizeof(int), h->s_main));
+  return 0;
+}
+
+int bgp_flag_merge_dev(bgp_handle* h, const double* flag_slot_dev) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!flag_slot_dev) return bgp_fail(h, -1, "bgp_flag_merge_dev: NULL slot");
+  return launch_flag_merge(h, h->s_main, h->dinfo, flag_slot_dev);
+}
+
+int bgp_flag_read(bgp_handle* h, int* flag_out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  int info = 0;
+  if ((rc = check_info(h, h->s_main, h->s_aux, h->dinfo, &info))) return rc;
+  if (flag_out) *flag_out = info;
+  return 0;
+}
+
+void* bgp_get_stream(bgp_handle* h, int which) {
+  if (!h) return nullptr;
+  return reinterpret_cast<void*>(which == 1 ? h->s_aux : h->s_main);
+}
+
+int bgp_update_panels_dev(bgp_handle* h, double* store_dev, const int64_t* desc, int count, const double* P_dev,
+                          int64_t ldp, int k, const double* abort_flag_dev) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!store_dev || !desc || !P_dev || count < 0 || k < 1)
@@ -1490,11 +1570,12 @@ int bgp_update_panels_dev(bgp_handle* h, double* store_dev, int64_t ld, const in
   BGP_HIP(h, hipEventRecord(ev, h->s_main));
   BGP_HIP(h, hipStreamWaitEvent(h->s_aux, ev, 0));
   const int tmode = k >= 256 ? 2 : 0;
+  const int* abort_flag = reinterpret_cast<const int*>(abort_flag_dev);
   for (int i = 0; i < count; ++i) {
-    const int64_t* d = desc + 4 * (int64_t)i;
+    const int64_t* d = desc + 5 * (int64_t)i;
     hipStream_t st = (i & 1) ? h->s_aux : h->s_main;
     const double* P = P_dev + d[3];
-    if ((rc = launch_gemm_nt(h, st, tmode, 128, store_dev + d[0], ld, P, ldp, P, ldp, d[1], d[2], k, 1))) return rc;
+    if ((rc = launch_gemm_nt(h, st, tmode, 128, store_dev + d[0], d[4], P, ldp, P, ldp, d[1], d[2], k, 1, abort_flag))) return rc;
   }
   // ... and the first waits for it, so that later work queued on the first stream sees every update
   if ((rc = sync_event(h, 1, &ev))) return rc;
@@ -1534,6 +1615,27 @@ int bgp_var_finish_dev(bgp_handle* h, const double* Xq_dev, int64_t M, int D, co
   FillParams p;
   if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
   return launch_rowdot_finish(h, h->s_main, ssq_dev, 1, M, Xq_dev, &p, min_var, out_dev);
+}
+
+namespace {
+__global__ void clock_samples_kernel(unsigned long long* out, int nsamp, int spin) {
+  for (int s = 0; s < nsamp; ++s) {
+    out[2 * s] = wall_clock64();
+    out[2 * s + 1] = clock64();
+    double a = 1.0 + s;
+    for (int i = 0; i < spin; ++i) a = __builtin_fma(a, 1.0000001, 1e-9);
+    if (a == 0.123) out[0] = 0;
+  }
+}
+}  // namespace
+
+int bgp_debug_clock_samples_dev(bgp_handle* h, uint64_t* out_dev, int nsamp, int spin) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!out_dev || nsamp < 1 || spin < 0) return bgp_fail(h, -1, "bgp_debug_clock_samples_dev: bad arguments");
+  hipLaunchKernelGGL(clock_samples_kernel, dim3(1), dim3(64), 0, h->s_aux, reinterpret_cast<unsigned long long*>(out_dev), nsamp, spin);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
 }
 
 int bgp_sync(bgp_handle* h) {

@@ -7,6 +7,10 @@
 // fp64 VALU ops per entry hidden behind it.  Replaces the >= 6 N^2 passes + N `torch.minimum`
 // launches of the reference (src/gp/wiener_kernel.py:21-22, RBFKernel/ScaleKernel/AddedDiag
 // at src/batt_models/cell_gp.py:32-36).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "bgp_internal.h"
 
 namespace {
@@ -31,19 +35,26 @@ __device__ const double EXP2_TBL[64] = {
     1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951,
 };
 
-// exp(x) for x <= 0 (finite):  x = k ln2/64 + r,  |r| <= ln2/128,  exp(x) = 2^(k>>6) T[k&63] e^r
+// exp(x) for x <= 0:  x = k ln2/64 + r,  |r| <= ln2/128,  exp(x) = 2^(k>>6) T[k&63] e^r
 // with e^r by a degree-5 Taylor polynomial (truncation r^6/720 <= 3.5e-17) and the scaling by
-// v_ldexp_f64 (correct gradual underflow).  12 fp64 VALU ops + one LDS table read per call -
-// the table-free degree-13 version cost 20 and made the fill VALU-bound at N = 131 072.
-__device__ __forceinline__ double exp_nonpos(double x, const double* __restrict__ tbl) {
+// v_ldexp_f64 (correct gradual underflow).  k comes out of the rounding itself: adding 1.5 * 2^52 to x * 64/ln2
+// rounds to nearest-even in the fp64 adder and leaves k as a two's-complement integer in the low mantissa word -
+// no v_rndne / v_cvt pair.  One LDS table read per call; `tbl` may be pre-multiplied by an output scale.
+// FINITE = false: NaN stays NaN (it has to poison Sigma, not vanish in a clamp) and -inf gives 0;
+// FINITE = true (the fill's interior tiles, whose points were checked when they were staged): one VALU op less.
+template <bool FINITE>
+__device__ __forceinline__ double exp_nonpos_t(double x, const double* __restrict__ tbl) {
   const double INV = 92.33248261689366;      // 64 / ln2
   const double L_HI = 0.01083042469326756;  // ln2/64, low 21 bits zero: k * L_HI is exact
   const double L_LO = 2.9815858269852933e-12;
-  double kd = __builtin_rint(x * INV);
+  const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+  const double LIM = -16777216.0;           // below: the result underflows to 0 anyway; keeps k inside 32 bits
+  x = FINITE ? __builtin_fmax(x, LIM) : ((x < LIM) ? LIM : x);
+  const double z = __builtin_fma(x, INV, MAGIC);
+  const int k = __double2loint(z);
+  const double kd = z - MAGIC;
   double r = __builtin_fma(kd, -L_HI, x);
   r = __builtin_fma(kd, -L_LO, r);
-  // k >= -2^17 keeps the int conversion and the exact reduction safe for huge |x| (result 0)
-  const int k = (int)__builtin_fmax(kd, -131072.0);
   const double t = tbl[k & 63];
   double p = 8.3333333333333332e-03;               // 1/5!
   p = __builtin_fma(p, r, 4.1666666666666664e-02);  // 1/4!
@@ -52,6 +63,10 @@ __device__ __forceinline__ double exp_nonpos(double x, const double* __restrict_
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(t * p, k >> 6);
+}
+
+__device__ __forceinline__ double exp_nonpos(double x, const double* __restrict__ tbl) {
+  return exp_nonpos_t<false>(x, tbl);
 }
 
 // sqrt(q), q >= 0, to ~1.5 ulp: v_rsq_f64 seed (2^-26) times q, then ONE residual correction with the seed's own
@@ -79,10 +94,11 @@ __device__ __forceinline__ double kfun(const double (&a)[DD], const double (&b)[
         q = __builtin_fma(df, df, q);
       }
     double e = exp_nonpos(-q, tbl);
+    // min^3/3 + |a - b| min^2/2  =  min^2 (max/2 - min/6): no cancellation (max/2 - min/6 >= min/3)
     double m = __builtin_fmin(a[0], b[0]);
-    double ad = __builtin_fabs(a[0] - b[0]);
-    double m2 = m * m;
-    double w = (m2 * m) * (1.0 / 3.0) + (ad * m2) * 0.5;
+    double mx = __builtin_fmax(a[0], b[0]);
+    double u = __builtin_fma(m, -1.0 / 6.0, 0.5 * mx);
+    double w = (m * m) * u;
     return __builtin_fma(s0, w, s1 * e);
   } else if (KID == BGP_KERNEL_MATERN32) {
     double q = 0.0;
@@ -158,8 +174,64 @@ __host__ int64_t lower_blocks(int nti, int ntj) {
   return (int64_t)FT_RATIO * (G * nti - G * (G - 1) / 2);
 }
 
+// The interior tiles' arithmetic (finite inputs guaranteed; `tbl` is pre-multiplied by the output scale, so the
+// exponential arrives scaled).  K0 with SORTED = true: the tile lies strictly below the diagonal of a matrix whose
+// time column is ascending, so min(t_i, t_j) = t_j and the integrated-Wiener term
+//   s_w (min^3/3 + |t_i - t_j| min^2/2) = (s_w t_j^2 / 2) t_i - s_w t_j^3 / 6 = A_j t_i + B_j
+// is ONE fma with two per-column constants staged next to the column point (w[0] = A_j, w[1] = B_j).
+template <int KID, int DD, bool SORTED>
+__device__ __forceinline__ double kfun_interior(const double (&a)[DD], const double (&b)[DD], const double (&w)[2], int D,
+                                                double s0, const double* __restrict__ tbl) {
+  if (KID == BGP_KERNEL_BATTGP) {
+    double q = 0.0;
+#pragma unroll
+    for (int d = 1; d < DD; ++d)
+      if (d < D) {
+        const double df = a[d] - b[d];
+        q = __builtin_fma(df, df, q);
+      }
+    const double e = exp_nonpos_t<true>(-q, tbl);  // s_r e^-q
+    if (SORTED) return __builtin_fma(w[0], a[0], w[1]) + e;
+    const double m = __builtin_fmin(a[0], b[0]);
+    const double mx = __builtin_fmax(a[0], b[0]);
+    const double u = __builtin_fma(m, -1.0 / 6.0, 0.5 * mx);
+    return __builtin_fma((s0 * m) * m, u, e);
+  } else if (KID == BGP_KERNEL_MATERN32) {
+    // the tiny seed keeps rsq finite at coincident points (r = 1e-150 there): no select on the critical path
+    double q = 1e-300;
+#pragma unroll
+    for (int d = 0; d < DD; ++d)
+      if (d < D) {
+        const double df = a[d] - b[d];
+        q = __builtin_fma(df, df, q);
+      }
+    const double y = __builtin_amdgcn_rsq(q);
+    double r = q * y;
+    r = __builtin_fma(__builtin_fma(-r, r, q), 0.5 * y, r);
+    const double se = exp_nonpos_t<true>(-r, tbl);  // s e^-r
+    return __builtin_fma(r, se, se);
+  } else {
+    double q = 0.0;
+#pragma unroll
+    for (int d = 0; d < DD; ++d)
+      if (d < D) {
+        const double df = a[d] - b[d];
+        q = __builtin_fma(df, df, q);
+      }
+    return exp_nonpos_t<true>(-q, tbl);
+  }
+}
+
+__device__ __forceinline__ bool not_finite(double v) { return !(__builtin_fabs(v) <= 1.7976931348623157e308); }
+
 // ABL != 0: ablation variants for tools/fill_ablate.hip only (1 = no kernel math, 2 = no stores)
-template <int KID, int DT, int ABL = 0>
+// UNR: unroll of the interior column loop.  Interior tiles store non-temporally: the matrix is written once and
+// next read by another kernel after > 100 GB of other traffic (+5-6 % on the store stream, tools/fill_gap_probe.py).
+//
+// What bounds this kernel (tools/fill_gap_probe.py with FILL_PROBE_CLOCK=1): while it runs the SMU holds the shader
+// clock at 1.0-1.4 GHz (2.39 GHz idle, >= 2.2 GHz under hipMemset or a pure fp64-FMA load), so its ~30 VALU
+// instructions per 8 bytes, not the store stream, set the pace - hence the lean interior arithmetic above.
+template <int KID, int DT, int ABL = 0, int UNR = 8>
 __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* __restrict__ x1,
                                                    int64_t n1, const double* __restrict__ x2,
                                                    int64_t n2, double* __restrict__ out, int64_t ld,
@@ -168,8 +240,14 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
   constexpr int DD = DT ? DT : BGP_MAX_DIM;
   const int D = DT ? DT : p.D;
   __shared__ double sB[FT_COLS][DD];
-  __shared__ double sT[64];
-  if (threadIdx.x < 64) sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
+  __shared__ double sW[FT_COLS][2];  // K0: A_j = s_w t_j^2 / 2, B_j = -s_w t_j^3 / 6
+  __shared__ double sT[64];          // 2^(i/64) ...
+  __shared__ double sTs[64];         // ... and the same times the output scale (s_r for K0, s otherwise)
+  const double oscale = (KID == BGP_KERNEL_BATTGP) ? p.s1 : p.s0;
+  if (threadIdx.x < 64) {
+    sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
+    sTs[threadIdx.x] = EXP2_TBL[threadIdx.x] * oscale;
+  }
 
   int ti, tj;
   if (lower) {
@@ -180,13 +258,20 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
   }
   const int64_t i0 = (int64_t)ti * FT_ROWS, j0 = (int64_t)tj * FT_COLS;
 
+  int bad = 0;  // a NaN / inf coordinate anywhere in the tile sends it down the general path
   for (int idx = threadIdx.x; idx < FT_COLS * DD; idx += 256) {
     int c = idx / DD, d = idx % DD;
     int64_t j = j0 + c;
     double v = 0.0;
     if (j < nv2 && d < D) {
       v = x2[j * D + d];
-      if (!(KID == BGP_KERNEL_BATTGP && d == 0)) v *= p.scale[d];
+      bad |= not_finite(v) ? 1 : 0;
+      if (KID == BGP_KERNEL_BATTGP && d == 0) {
+        sW[c][0] = (0.5 * p.s0) * v * v;
+        sW[c][1] = (-p.s0 / 6.0) * v * v * v;
+      } else {
+        v *= p.scale[d];
+      }
     }
     sB[c][d] = v;
   }
@@ -195,30 +280,44 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
   double a0[DD], a1[DD];
   load_point<KID, DD>(x1, i, nv1, D, p, a0);
   load_point<KID, DD>(x1, i + 1, nv1, D, p, a1);
-  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < DD; ++d) bad |= (not_finite(a0[d]) || not_finite(a1[d])) ? 1 : 0;
+  bad = __syncthreads_or(bad);
 
   const double s0 = p.s0, s1 = p.s1, noise = p.noise;
 
   // Fast path for the vast majority of tiles: completely inside the valid region and off the
   // diagonal => no predicates, no padding logic, one branch-free basic block of 32 column steps.
   const bool touches_diag = add_diag && (j0 < i0 + FT_ROWS) && (i0 < j0 + FT_COLS);
-  const bool interior = vec_ok && !touches_diag && (i0 + FT_ROWS <= nv1) && (i0 + FT_ROWS <= n1) &&
+  const bool interior = vec_ok && !touches_diag && !bad && (i0 + FT_ROWS <= nv1) && (i0 + FT_ROWS <= n1) &&
                         (j0 + FT_COLS <= nv2) && (j0 + FT_COLS <= n2);
   if (interior) {
     double* dst = out + i + j0 * ld;
-#pragma unroll 8
-    for (int c = 0; c < FT_COLS; ++c) {
-      double b[DD];
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    auto columns = [&](auto sorted_tag) {
+      constexpr bool SORTED = decltype(sorted_tag)::value;
+#pragma unroll UNR
+      for (int c = 0; c < FT_COLS; ++c) {
+        double b[DD], w[2] = {0.0, 0.0};
 #pragma unroll
-      for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
-      double v0 = (ABL & 1) ? a0[1] + b[1] : kfun<KID, DD>(a0, b, D, s0, s1, sT);
-      double v1 = (ABL & 1) ? a1[1] - b[1] : kfun<KID, DD>(a1, b, D, s0, s1, sT);
-      if (ABL & 2) {
-        if (v0 + v1 == 1.2345e300) out[0] = v0;
-      } else {
-        *reinterpret_cast<double2*>(dst + (int64_t)c * ld) = make_double2(v0, v1);
+        for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
+        if (SORTED) {
+          w[0] = sW[c][0];
+          w[1] = sW[c][1];
+        }
+        double v0 = (ABL & 1) ? a0[1] + b[1] : kfun_interior<KID, DD, SORTED>(a0, b, w, D, s0, sTs);
+        double v1 = (ABL & 1) ? a1[1] - b[1] : kfun_interior<KID, DD, SORTED>(a1, b, w, D, s0, sTs);
+        if (ABL & 2) {
+          if (v0 + v1 == 1.2345e300) out[0] = v0;
+        } else {
+          v2d vv = {v0, v1};
+          __builtin_nontemporal_store(vv, reinterpret_cast<v2d*>(dst + (int64_t)c * ld));
+        }
       }
-    }
+    };
+    // strictly below the diagonal of a matrix with ascending times (x1 == x2 there): min(t_i, t_j) = t_j
+    if (KID == BGP_KERNEL_BATTGP && p.t_sorted && lower && i0 >= j0 + FT_COLS) columns(std::true_type{});
+    else columns(std::false_type{});
     return;
   }
 
@@ -268,9 +367,17 @@ int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t
   if (nblocks > 0x7fffffffLL) return -1;
   const int vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   dim3 grid((unsigned)nblocks), block(256);
-  if (p.D == 4)
-    hipLaunchKernelGGL((fill_kernel<KID, 4>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower,
-                       add_diag, nv1, nv2, nti, ntj, vec_ok);
+  static const int unr = getenv("BGP_FILL_UNROLL") ? atoi(getenv("BGP_FILL_UNROLL")) : 0;  // experiment knob
+#define FILL_UNR(U)                                                                                          \
+  hipLaunchKernelGGL((fill_kernel<KID, 4, 0, U>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag, \
+                     nv1, nv2, nti, ntj, vec_ok)
+  // measured at N = 131 072 (steady GB/s by unroll 2 / 4 / 8 / 16): K0 5810 / 5750 / 5640 / 5780, Matern 5440 / 5570 / 5440 / 5470
+  constexpr int UNR_DEFAULT = (KID == BGP_KERNEL_BATTGP) ? 2 : 4;
+  if (p.D == 4 && unr == 2) FILL_UNR(2);
+  else if (p.D == 4 && unr == 4) FILL_UNR(4);
+  else if (p.D == 4 && unr == 8) FILL_UNR(8);
+  else if (p.D == 4 && unr == 16) FILL_UNR(16);
+  else if (p.D == 4) FILL_UNR(UNR_DEFAULT);
   else
     hipLaunchKernelGGL((fill_kernel<KID, 0>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower,
                        add_diag, nv1, nv2, nti, ntj, vec_ok);

@@ -21,6 +21,7 @@ struct FillParams {
   double s0;       // s_wiener (K0) or outputscale s (K1..K3)
   double s1;       // s_rbf (K0)
   double scale[BGP_MAX_DIM];  // per-column input scale: 1/(l*sqrt 2) (RBF) or sqrt(3)/l (Matern); K0 col 0 unused
+  int t_sorted;    // K0 training fill: column 0 of X is ascending, so below the diagonal min(t_i, t_j) = t_j
 };
 
 // Storage of the in-place covariance / factor.  The columns are cut into slabs of width W; slab g
@@ -84,6 +85,7 @@ struct bgp_handle {
   int D = 0;
   bool fitted = false;
   bool has_data = false;     // X, y were uploaded through THIS life of the handle (a revived pooled handle starts without)
+  bool t_sorted = false;     // column 0 of the resident X is ascending (checked on the device at upload)
   bool alpha_ready = false;
   double jitter_used = 0.0, lml = 0.0;
   // device buffers
@@ -177,4 +179,7 @@ int grad_nacc();
 int64_t grad_blocks(int64_t n);
 int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n,
                        const double* S, int64_t lds_, const double* alpha, double* part, double* out);
+int launch_flag_store(bgp_handle* h, hipStream_t st, const int* info, double* slot);
+int launch_flag_merge(bgp_handle* h, hipStream_t st, int* info, const double* slot);
+int launch_check_sorted(bgp_handle* h, hipStream_t st, const double* x, int64_t n, int D, int* flag);  // *flag = 1 if a descent is found
 int launch_set_identity(bgp_handle* h, hipStream_t st, double* B, int64_t ld, int64_t n);

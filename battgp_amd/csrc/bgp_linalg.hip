@@ -762,7 +762,45 @@ __global__ __launch_bounds__(256) void copy_panel_kernel(const double* __restric
   *reinterpret_cast<double2*>(dst + r + c * ldd) = *reinterpret_cast<const double2*>(src + r + c * lds_);
 }
 
+// *flag |= 1 if column 0 of the row-major X[n, D] is not ascending (NaN counts as a descent)
+__global__ __launch_bounds__(256) void check_sorted_kernel(const double* __restrict__ x, int64_t n, int D, int* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i + 1 < n && !(x[i * D] <= x[(i + 1) * D])) atomicOr(flag, 1);
+}
+
+// failing-minor flag of the sharded factorisation: dst (an 8-byte slot behind a packed panel) <- *info
+__global__ void flag_store_kernel(const int* __restrict__ info, int* __restrict__ dst) {
+  dst[0] = *info;
+  dst[1] = 0;
+}
+
+// a rank that receives a panel whose flag is set poisons its own pipeline too
+__global__ void flag_merge_kernel(int* __restrict__ info, const int* __restrict__ src) {
+  if (*info == 0 && *src != 0) *info = *src;
+}
+
 }  // namespace
+
+int launch_check_sorted(bgp_handle* h, hipStream_t st, const double* x, int64_t n, int D, int* flag) {
+  BGP_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
+  if (n > 1) {
+    hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, D, flag);
+    BGP_HIP(h, hipGetLastError());
+  }
+  return 0;
+}
+
+int launch_flag_store(bgp_handle* h, hipStream_t st, const int* info, double* slot) {
+  hipLaunchKernelGGL(flag_store_kernel, dim3(1), dim3(1), 0, st, info, reinterpret_cast<int*>(slot));
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+int launch_flag_merge(bgp_handle* h, hipStream_t st, int* info, const double* slot) {
+  hipLaunchKernelGGL(flag_merge_kernel, dim3(1), dim3(1), 0, st, info, reinterpret_cast<const int*>(slot));
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
 
 int launch_diag_in(bgp_handle* h, hipStream_t st, const double* Akk, int64_t lda, double* D, int64_t ldd, int nbk) {
   hipLaunchKernelGGL(diag_in_kernel, dim3((unsigned)nbk), dim3(256), 0, st, Akk, lda, D, ldd, nbk);

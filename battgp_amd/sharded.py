@@ -1,33 +1,44 @@
 """One exact GP whose covariance matrix is too large for a single GPU: column-panel block-cyclic
 Cholesky over the ranks of a ``torch.distributed`` group (backend "nccl" = RCCL over xGMI; "gloo" in
-the CPU tests).  BASELINE config 4 (N = 262 144 on 4 x MI355X); SURVEY section 8(e).
+the CPU tests).  BASELINE config 4 (N = 262 144 on 4 x MI355X); the reference's
+one-GP-over-several-GPUs switch (``n_devices``, ``src/batt_models/cell_gp.py:37-47``).
 
 Distribution.  The matrix is cut into column panels of width ``nb``; panel ``j`` lives on rank
-``j % world`` with ALL its rows from the diagonal down plus the 64-row augmented block whose row 0
-carries ``y^T``.  Right-looking factorisation, one exchange per panel step:
+``j % world`` and keeps ONLY the rows from its own diagonal down plus the 64-row augmented block whose row 0
+carries ``y^T`` - a rank holds ~``4 N^2 / world`` bytes (69 GB per rank at N = 262 144, world = 4).
+Right-looking factorisation, one exchange per panel step:
 
     for k in panels:                                   (panel k is already on every rank)
         owner(k+1): C_{k+1} -= P_k ...; factor panel k+1 locally; pack it                     (look-ahead)
         all ranks:  start the broadcast of packed panel k+1 [(Npad + 64 - (k+1) nb) x nb + flag]  <- RCCL, async
         every rank: C_j -= P_k[rows >= j nb] P_k[rows of j]^T  for each of ITS panels j > k   (MFMA)
-        wait for the broadcast
 
-so each rank receives ~4 N^2 (w-1)/w bytes in total and runs 1/w of the N^3/3 flops.  The forward
-solve rides along in the augmented row (``z^T`` comes out of the factorisation), ``log det`` and the
-``z`` segments are combined with small all-reduces.  Prediction pushes the query block through the
-factor right-looking: the owner of panel k finishes ``E_k`` (reduce of the pending contributions),
-updates its own accumulator for all later columns, and adds its share of ``mean = V^T z`` and
-``var = k_** - rowsumsq(V^T)``.
+so each rank receives ~4 N^2 (w-1)/w bytes in total and runs 1/w of the N^3/3 flops.
 
-The numerical work is done by a *backend*: ``DeviceBackend`` drives the HIP kernels of libbattgp.so
-on torch-owned device buffers (torch = container + communicator only); the tests supply a numpy
-backend to check the distributed algorithm on CPU/gloo.
+The whole factorisation is ENQUEUED: no host synchronisation inside the panel loop.  The engine's HIP stream is
+handed to torch as an ``ExternalStream`` and made current, so torch's buffer operations and its RCCL collectives are
+ordered with the engine's kernels by the streams themselves: the broadcast of panel k+1 waits (on the device) for the
+kernels that pack it and runs on RCCL's stream next to the rank-``nb`` updates of step k; the kernels of step k+1 wait
+(on the device) for that broadcast.  A failed pivot sets a device flag that turns the owner's later kernels into no-ops
+and travels behind the packed panel to poison the other ranks' pipelines; the host looks at the flags ONCE per
+factorisation attempt (an all-reduce MAX) and walks the jitter ladder like the single-GPU engine.
+
+The forward solve rides along in the augmented row (``z^T`` comes out of the factorisation), ``log det`` and the ``z``
+segments are combined with small all-reduces.  Prediction pushes the query block through the factor right-looking:
+the owner of panel k finishes ``E_k`` (reduce of the pending contributions), updates its own accumulator for all later
+columns, and adds its share of ``mean = V^T z`` and ``var = k_** - rowsumsq(V^T)``.
+
+The numerical work is done by a *backend*: ``DeviceBackend`` drives the HIP kernels of libbattgp.so on torch-owned
+device buffers (torch = container + communicator only); the tests supply a numpy backend to check the distributed
+algorithm on CPU/gloo.
 """
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
+import time
 
 import numpy as np
 
@@ -45,7 +56,7 @@ class PanelLayout:
         self.n, self.nb, self.world = n, nb, world
         self.npad = round_up(n, 64)
         self.npanels = -(-self.npad // nb)
-        self.nrows = self.npad + AUG  # leading dimension of every stored column
+        self.nrows = self.npad + AUG  # rows of panel 0: the padded matrix + the augmented block
 
     def owner(self, j: int) -> int:
         return j % self.world
@@ -66,9 +77,25 @@ class PanelLayout:
         """rows of panel j from its diagonal down, augmented block included"""
         return self.nrows - self.col0(j)
 
+    def ld(self, j: int) -> int:
+        """leading dimension of stored panel j: its own height (no rows above its diagonal block are kept), bumped off
+        large power-of-two strides (all columns of a tile in one HBM channel)"""
+        r = self.rows_from(j)
+        return r + 64 if (r >= 2048 and r % 512 == 0) else r
+
+    def offsets(self, rank: int) -> tuple[dict, int]:
+        """element offset of every local panel in the rank's store, and the store's size"""
+        off, total = {}, 0
+        for j in self.local_panels(rank):
+            off[j] = total
+            total += self.ld(j) * self.width(j)
+        return off, total
+
 
 class DeviceBackend:
-    """HIP kernels through the C-ABI on torch-owned device memory."""
+    """HIP kernels through the C-ABI on torch-owned device memory.  Every torch operation on those buffers and every
+    collective is issued with the ENGINE's stream current (``torch.cuda.ExternalStream`` around ``bgp_get_stream``), so
+    kernels, copies and RCCL calls are ordered on the device."""
 
     def __init__(self, engine, device):
         import torch
@@ -80,107 +107,111 @@ class DeviceBackend:
         self.lib = _lib.load()
         self.h = engine._h
         self.device = device
+        ptr = self.lib.bgp_get_stream(self.h, 0)
+        self.stream = torch.cuda.ExternalStream(int(ptr), device=device)
+
+    def on_stream(self):
+        return self.torch.cuda.stream(self.stream)
 
     def _chk(self, rc, what):
         self.eng._check(rc, what)
 
     def zeros(self, n):
-        # the fill runs on torch's stream, the engine's kernels on their own: finish it before handing
-        # the buffer to the engine
-        t = self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
-        self.after_comm()
-        return t
+        with self.on_stream():
+            return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
 
     def empty(self, n):
-        return self.torch.empty(int(n), dtype=self.torch.float64, device=self.device)
+        with self.on_stream():
+            return self.torch.empty(int(n), dtype=self.torch.float64, device=self.device)
 
     def upload(self, a):
-        t = self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
-        self.after_comm()
-        return t
+        with self.on_stream():
+            return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
 
     def to_host(self, t):
-        return t.detach().cpu().numpy()
+        with self.on_stream():
+            return t.detach().cpu().numpy()
 
     def sync(self):
-        """drain the engine's streams (its kernels run outside torch's stream)"""
+        """drain the engine's streams"""
         self._chk(self.lib.bgp_sync(self.h), "bgp_sync")
-
-    def after_comm(self):
-        """RCCL work is ordered on torch's stream, the HIP kernels run on the engine's: make the received
-        data visible before the next engine launch"""
-        self.torch.cuda.current_stream(self.device).synchronize()
 
     @staticmethod
     def _p(t, off=0):
         return C.c_void_p(t.data_ptr() + 8 * int(off))
 
-    def fill_panel(self, store, ld, lcol0, x_dev, n, d, col0, ncols, rows, y_dev, extra_diag):
-        """store[(i-col0) ... ]: columns [col0, col0+ncols) rows [col0, npad) + augmented block"""
-        base = lcol0 * ld + col0
+    # ---- factorisation ------------------------------------------------------------------------------
+    def fill_panel(self, store, off, ld, x_dev, n, d, col0, ncols, rows, y_dev, extra_diag):
+        """panel [rows, ncols] at store[off:], leading dimension ld: Sigma rows [col0, npad) of columns
+        [col0, col0 + ncols), then the augmented block"""
         self._chk(
-            self.lib.bgp_fill_block_dev(self.h, self._p(x_dev), n, d, col0, col0, rows - AUG, ncols, self._p(store, base), ld, float(extra_diag)),
+            self.lib.bgp_fill_block_dev(self.h, self._p(x_dev), n, d, col0, col0, rows - AUG, ncols, self._p(store, off), ld, float(extra_diag)),
             "bgp_fill_block_dev",
         )
         self._chk(
-            self.lib.bgp_aug_rows_dev(self.h, self._p(y_dev), n, col0, ncols, self._p(store, lcol0 * ld + (ld - AUG)), ld),
+            self.lib.bgp_aug_rows_dev(self.h, self._p(y_dev), n, col0, ncols, self._p(store, off + rows - AUG), ld),
             "bgp_aug_rows_dev",
         )
 
-    def factor_panel(self, store, ld, lcol0, col0, rows, nbk, inv):
-        info = C.c_int(0)
-        self._chk(
-            self.lib.bgp_factor_panel_dev(self.h, self._p(store, lcol0 * ld + col0), ld, rows, nbk, self._p(inv), C.byref(info)),
-            "bgp_factor_panel_dev",
-        )
-        return int(info.value)
+    def flag_reset(self):
+        self._chk(self.lib.bgp_flag_reset_dev(self.h), "bgp_flag_reset_dev")
 
-    def factor_pack(self, store, ld, lcol0, col0, rows, nbk, inv, pbuf):
-        """factor the panel and leave its packed copy in pbuf (one C call; see bgp_factor_pack_panel_dev)"""
-        info = C.c_int(0)
+    def factor_pack(self, store, off, ld, rows, nbk, inv, pbuf, col0):
+        """factor the panel (asynchronously) and leave its packed copy + the failure flag slot in pbuf"""
         self._chk(
-            self.lib.bgp_factor_pack_panel_dev(
-                self.h, self._p(store, lcol0 * ld + col0), ld, rows, nbk, self._p(inv), self._p(pbuf), C.byref(info)
+            self.lib.bgp_factor_pack_panel_async_dev(
+                self.h, self._p(store, off), ld, rows, nbk, self._p(inv), self._p(pbuf), col0, self._p(pbuf, nbk * rows)
             ),
-            "bgp_factor_pack_panel_dev",
-        )
-        return int(info.value)
-
-    def pack_panel(self, store, ld, lcol0, col0, rows, nbk, pbuf):
-        """pbuf[r + c*rows] = store[(col0 + r) + (lcol0 + c)*ld]"""
-        t = self.torch
-        src = store.as_strided((nbk, rows), (ld, 1), lcol0 * ld + col0)
-        pbuf[: nbk * rows].view(nbk, rows).copy_(src)
-        t.cuda.current_stream(self.device).synchronize()
-
-    def update_panel(self, store, ld, lcol0, colj, rows_j, nbj, pbuf, ldp, off, nbk):
-        self._chk(
-            self.lib.bgp_gemm_nt_sub_async_dev(
-                self.h, self._p(store, lcol0 * ld + colj), ld, self._p(pbuf, off), ldp, self._p(pbuf, off), ldp, rows_j, nbj, nbk, 1
-            ),
-            "bgp_gemm_nt_sub_async_dev",
+            "bgp_factor_pack_panel_async_dev",
         )
 
-    def update_panels(self, store, ld, items, pbuf, ldp, nbk):
-        """items: (lcol0, colj, rows_j, nbj, p_off) per local panel - all updates of one step in one C call"""
+    def flag_merge(self, pbuf, idx):
+        self._chk(self.lib.bgp_flag_merge_dev(self.h, self._p(pbuf, idx)), "bgp_flag_merge_dev")
+
+    def flag_read(self) -> int:
+        out = C.c_int(0)
+        self._chk(self.lib.bgp_flag_read(self.h, C.byref(out)), "bgp_flag_read")
+        return int(out.value)
+
+    def update_panels(self, store, items, pbuf, ldp, nbk, flag_idx):
+        """items: (c_off, ldc, rows_j, nbj, p_off) per local panel - all updates of one step in one C call"""
         if not items:
             return
-        desc = np.ascontiguousarray([[lc * ld + cj, rows_j, nbj, off] for lc, cj, rows_j, nbj, off in items], dtype=np.int64)
+        desc = np.ascontiguousarray([[c_off, rows_j, nbj, p_off, ldc] for c_off, ldc, rows_j, nbj, p_off in items], dtype=np.int64)
         self._chk(
             self.lib.bgp_update_panels_dev(
-                self.h, self._p(store), ld, desc.ctypes.data_as(C.POINTER(C.c_int64)), len(items), self._p(pbuf), ldp, nbk
+                self.h, self._p(store), desc.ctypes.data_as(C.POINTER(C.c_int64)), len(items), self._p(pbuf), ldp, nbk,
+                self._p(pbuf, flag_idx) if flag_idx is not None else None,
             ),
             "bgp_update_panels_dev",
         )
 
-    def diag_logsum(self, store, ld, lcol0, col0, nbk) -> float:
+    def diag_logsum(self, store, off, ld, nbk) -> float:
         out = C.c_double(0.0)
-        self._chk(self.lib.bgp_diag_logsum_dev(self.h, self._p(store, lcol0 * ld + col0), ld, nbk, C.byref(out)), "bgp_diag_logsum_dev")
+        self._chk(self.lib.bgp_diag_logsum_dev(self.h, self._p(store, off), ld, nbk, C.byref(out)), "bgp_diag_logsum_dev")
         return float(out.value)
 
-    def aug_row(self, store, ld, lcol0, nbk):
+    def aug_row(self, store, off, ld, rows, nbk):
         """z segment = row 0 of the augmented block under the panel (strided view, copied)"""
-        return store.as_strided((nbk,), (ld,), lcol0 * ld + (ld - AUG)).clone()
+        with self.on_stream():
+            return store.as_strided((nbk,), (ld,), off + rows - AUG).clone()
+
+    # ---- collectives (issued with the engine's stream current) ------------------------------------------
+    def bcast_start(self, dist, t, src):
+        with self.on_stream():
+            return dist.broadcast(t, src=src, async_op=True)
+
+    def bcast_wait(self, work):
+        with self.on_stream():
+            work.wait()  # device-side wait of the engine's stream; the host does not block (RCCL)
+
+    def allreduce(self, dist, t, op=None):
+        with self.on_stream():
+            dist.all_reduce(t) if op is None else dist.all_reduce(t, op=op)
+
+    def reduce(self, dist, t, dst):
+        with self.on_stream():
+            dist.reduce(t, dst=dst)
 
     # ---- prediction ---------------------------------------------------------------------------
     def cross_fill(self, xq_dev, m, mpad, x_dev, n, d, npad, out, lde):
@@ -188,18 +219,16 @@ class DeviceBackend:
         p = self.lib.bgp_fill_dev
         self._chk(p(self.h, self._p(xq_dev), m, self._p(x_dev), n, d, self._p(out), lde, 0, 0.0), "bgp_fill_dev")
 
-    def solve_panel(self, e, lde, ecol0, me, store, ld, lcol0, col0, nbk, inv):
+    def solve_panel(self, e, eoff, lde, me, store, off, ld, nbk, inv):
         self._chk(
-            self.lib.bgp_solve_panel_dev(self.h, self._p(e, ecol0 * lde), lde, me, self._p(store, lcol0 * ld + col0), ld, nbk, self._p(inv)),
+            self.lib.bgp_solve_panel_dev(self.h, self._p(e, eoff), lde, me, self._p(store, off), ld, nbk, self._p(inv)),
             "bgp_solve_panel_dev",
         )
 
-    def update_rows(self, w, lde, wcol0, me, ek, ldek, store, ld, lcol0, row0, nrows, nbk):
-        # W[:, wcol0 : wcol0+nrows] -= E_k L[row0 : row0+nrows, panel k]^T
+    def update_rows(self, w, woff, lde, me, ek, ldek, store, off, ld, nrows, nbk):
+        # W[:, cols] -= E_k L[rows, panel k]^T   (store[off:] = the first of those rows of the panel)
         self._chk(
-            self.lib.bgp_gemm_nt_sub_async_dev(
-                self.h, self._p(w, wcol0 * lde), lde, self._p(ek), ldek, self._p(store, lcol0 * ld + row0), ld, me, nrows, nbk, 0
-            ),
+            self.lib.bgp_gemm_nt_sub_async_dev(self.h, self._p(w, woff), lde, self._p(ek), ldek, self._p(store, off), ld, me, nrows, nbk, 0),
             "bgp_gemm_nt_sub_async_dev",
         )
 
@@ -207,17 +236,34 @@ class DeviceBackend:
         """sum of squares of a vector, on the device (a 1 x n row block through the row-dot kernel)"""
         out = self.zeros(1)
         self._chk(self.lib.bgp_rowdot_dev(self.h, self._p(v), 1, 1, int(n), None, self._p(out)), "bgp_rowdot_dev")
-        self.sync()
-        return float(out[0])
+        return float(self.to_host(out)[0])
 
     def var_finish(self, xq_dev, m, d, ssq, min_var):
         out = self.empty(m)
         self._chk(self.lib.bgp_var_finish_dev(self.h, self._p(xq_dev), m, d, self._p(ssq), float(min_var), self._p(out)), "bgp_var_finish_dev")
-        self.sync()
         return out
 
-    def rowdot(self, e, lde, m, n, vec, out):
-        self._chk(self.lib.bgp_rowdot_dev(self.h, self._p(e), lde, m, n, self._p(vec) if vec is not None else None, self._p(out)), "bgp_rowdot_dev")
+    def rowdot(self, e, lde, m, n, vec, voff, out):
+        self._chk(
+            self.lib.bgp_rowdot_dev(self.h, self._p(e), lde, m, n, self._p(vec, voff) if vec is not None else None, self._p(out)),
+            "bgp_rowdot_dev",
+        )
+
+    def add_into(self, acc, t):
+        with self.on_stream():
+            acc += t
+
+    def copy_into(self, dst, src):
+        with self.on_stream():
+            dst.copy_(src)
+
+    def set_segment(self, vec, c0, seg):
+        with self.on_stream():
+            vec[c0 : c0 + seg.shape[0]] = seg
+
+    def scalar(self, value):
+        with self.on_stream():
+            return self.torch.full((1,), float(value), dtype=self.torch.float64, device=self.device)
 
 
 class ShardedExactGP:
@@ -229,6 +275,8 @@ class ShardedExactGP:
         self.lay = None
         self.lml = None
         self.jitter = 0.0
+        self._times = {}
+        self._shape = None
 
     def set_hyp(self, hyp) -> None:
         """New hyper-parameters for the next :meth:`fit` (every rank must pass the same vector)."""
@@ -237,52 +285,51 @@ class ShardedExactGP:
         if eng is not None:
             eng.set_hyp(self.hyp)
 
-    # ---- collectives (torch.distributed on backend buffers; numpy buffers are wrapped in place) ------
-    @staticmethod
-    def _t(buf):
-        if isinstance(buf, np.ndarray):
-            import torch
+    def timers(self) -> dict:
+        """host wall-clock of the last fit / predict on this rank (seconds)"""
+        return dict(self._times)
 
-            return torch.from_numpy(buf)
-        return buf
-
-    def _bcast(self, t, src):
-        if self.dist is not None:
-            self.dist.broadcast(self._t(t), src=src)
-            self.be.after_comm()
-
-    def _allreduce(self, t):
-        if self.dist is not None:
-            self.dist.all_reduce(self._t(t))
-            self.be.after_comm()
-
-    def _reduce(self, t, dst):
-        if self.dist is not None:
-            self.dist.reduce(self._t(t), dst=dst)
-            self.be.after_comm()
+    def close(self) -> None:
+        eng = getattr(self, "engine", None)
+        if eng is not None:
+            self.be.sync()
+            self.store = self.pbufs = self.inv = self.z = None
+            eng.close()
+            self.engine = None
 
     # ---- fit ------------------------------------------------------------------------------------
+    def _allocate(self, n: int, d: int):
+        lay = self.lay = PanelLayout(n, self.nb, self.world)
+        if self._shape == (n, d):
+            return lay
+        be = self.be
+        mine = lay.local_panels(self.rank)
+        self.poff, total = lay.offsets(self.rank)
+        self.store = be.empty(max(1, total))
+        self.inv = {j: be.empty((lay.width(j) // 64) * 4096) for j in mine}
+        # packed panel + failing-minor flag slot; two of them: the broadcast of panel k+1 is in flight while panel k is read
+        self.pbufs = [be.empty(lay.nb * lay.nrows + 1), be.empty(lay.nb * lay.nrows + 1)]
+        self._shape = (n, d)
+        return lay
+
     def fit(self, x: np.ndarray, y: np.ndarray) -> float:
+        t_start = time.perf_counter()
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
         n, d = x.shape
         be = self.be
-        lay = self.lay = PanelLayout(n, self.nb, self.world)
+        lay = self._allocate(n, d)
         self.n, self.d = n, d
-        ld = lay.nrows
         mine = lay.local_panels(self.rank)
         self.x_dev, self.y_dev = be.upload(x), be.upload(y)
-        ncols_local = sum(lay.width(j) for j in mine)
-        self.store = be.empty(max(1, ncols_local) * ld)
-        self.lcol0 = {j: lay.local_index(j) * lay.nb for j in mine}
-        self.inv = {j: be.empty((lay.width(j) // 64) * 4096) for j in mine}
-        pbufs = [be.empty(lay.nb * ld + 1), be.empty(lay.nb * ld + 1)]  # packed panel + failing-minor flag
 
         jitter = 0.0
         for attempt in range(self.max_tries + 1):
+            be.flag_reset()
             for j in mine:
-                be.fill_panel(self.store, ld, self.lcol0[j], self.x_dev, n, d, lay.col0(j), lay.width(j), lay.rows_from(j), self.y_dev, jitter)
-            info = self._factor(pbufs)
+                be.fill_panel(self.store, self.poff[j], lay.ld(j), self.x_dev, n, d, lay.col0(j), lay.width(j), lay.rows_from(j), self.y_dev, jitter)
+            self._enqueue_factorisation()
+            info = self._collect_flag()  # the ONE host synchronisation of the attempt
             if info == 0:
                 break
             if attempt == self.max_tries:
@@ -297,37 +344,44 @@ class ShardedExactGP:
         logdet = 0.0
         for j in mine:
             c0, w = lay.col0(j), lay.width(j)
-            z[c0 : c0 + w] = be.aug_row(self.store, ld, self.lcol0[j], w)
-            logdet += be.diag_logsum(self.store, ld, self.lcol0[j], c0, w)
-        ld_t = be.zeros(1)
-        ld_t[0] = logdet
-        self._allreduce(z)
-        self._allreduce(ld_t)
+            be.set_segment(z, c0, be.aug_row(self.store, self.poff[j], lay.ld(j), lay.rows_from(j), w))
+            logdet += be.diag_logsum(self.store, self.poff[j], lay.ld(j), w)
+        ld_t = be.scalar(logdet)
+        if self.dist is not None:
+            be.allreduce(self.dist, z)
+            be.allreduce(self.dist, ld_t)
         self.z = z
         zz = be.sumsq(z, lay.npad)
-        self.lml = -0.5 * zz - float(ld_t[0]) - 0.5 * n * math.log(2.0 * math.pi)
+        self.lml = -0.5 * zz - float(be.to_host(ld_t)[0]) - 0.5 * n * math.log(2.0 * math.pi)
+        self._times["fit_s"] = time.perf_counter() - t_start
         return self.lml
 
-    def _factor(self, pbufs) -> int:
+    def _collect_flag(self) -> int:
+        """failing leading minor seen by ANY rank (0 = none): drains this rank's pipeline, then one MAX all-reduce"""
+        flag = self.be.flag_read()
+        if self.dist is None:
+            return flag
+        t = self.be.scalar(flag)
+        self.be.allreduce(self.dist, t, op=self.dist.ReduceOp.MAX)
+        return int(self.be.to_host(t)[0])
+
+    def _enqueue_factorisation(self) -> None:
         """Right-looking factorisation with a one-panel look-ahead on the exchange: while every rank applies
         panel k to its own panels, the owner of panel k+1 has already updated, factored and packed that
-        panel and its broadcast is in flight (``async_op``), so the xGMI transfer of panel k+1 hides behind
-        the rank-nb updates of step k.  ONE collective per step: the failing-minor flag travels as the
-        element behind the packed panel."""
-        lay, be, ld = self.lay, self.be, self.lay.nrows
+        panel and its broadcast is in flight, so the xGMI transfer of panel k+1 hides behind the rank-nb updates of
+        step k.  ONE collective per step (the failing-minor flag travels as the element behind the packed panel) and
+        no host synchronisation: everything is ordered by the engine's stream."""
+        lay, be = self.lay, self.be
         mine = set(lay.local_panels(self.rank))
+        pbufs = self.pbufs
 
         def factor_and_pack(k, buf):
-            c0, nbk, rows = lay.col0(k), lay.width(k), lay.rows_from(k)
-            info = be.factor_pack(self.store, ld, self.lcol0[k], c0, rows, nbk, self.inv[k], buf)
-            buf[nbk * rows] = float(info + c0 if info else 0)
-            be.after_comm()
+            be.factor_pack(self.store, self.poff[k], lay.ld(k), lay.rows_from(k), lay.width(k), self.inv[k], buf, lay.col0(k))
 
         def start_bcast(k, buf):
             if self.dist is None:
                 return None
-            n_el = lay.width(k) * lay.rows_from(k) + 1
-            return self.dist.broadcast(self._t(buf[:n_el]), src=lay.owner(k), async_op=True)
+            return be.bcast_start(self.dist, buf[: lay.width(k) * lay.rows_from(k) + 1], lay.owner(k))
 
         if self.rank == lay.owner(0):
             factor_and_pack(0, pbufs[0])
@@ -335,32 +389,30 @@ class ShardedExactGP:
         for k in range(lay.npanels):
             cur, nxt = pbufs[k % 2], pbufs[(k + 1) % 2]
             c0, nbk, rows = lay.col0(k), lay.width(k), lay.rows_from(k)
+            flag_idx = nbk * rows
             if work is not None:
-                work.wait()
-                be.after_comm()
-            flag = float(cur[nbk * rows])
-            if flag != 0.0:
-                return int(flag)
+                be.bcast_wait(work)
+            if self.rank != lay.owner(k):
+                be.flag_merge(cur, flag_idx)  # a failure upstream poisons this rank's pipeline as well
             if k == lay.npanels - 1:
                 break
+
+            def item(j):
+                return (self.poff[j], lay.ld(j), lay.rows_from(j), lay.width(j), lay.col0(j) - c0)
+
             todo = sorted(p for p in mine if p > k)
             if (k + 1) in mine:  # look-ahead: my next panel first, then factor and ship it
-                cj, nbj = lay.col0(k + 1), lay.width(k + 1)
-                be.update_panel(self.store, ld, self.lcol0[k + 1], cj, lay.rows_from(k + 1), nbj, cur, rows, cj - c0, nbk)
-                be.sync()
+                be.update_panels(self.store, [item(k + 1)], cur, rows, nbk, flag_idx)
                 factor_and_pack(k + 1, nxt)
                 todo.remove(k + 1)
             work = start_bcast(k + 1, nxt)
-            be.update_panels(
-                self.store, ld, [(self.lcol0[j], lay.col0(j), lay.rows_from(j), lay.width(j), lay.col0(j) - c0) for j in todo], cur, rows, nbk
-            )
-            be.sync()
-        return 0
+            be.update_panels(self.store, [item(j) for j in todo], cur, rows, nbk, flag_idx)
 
     # ---- predict ----------------------------------------------------------------------------------
     def predict(self, xq: np.ndarray, min_var: float = 1e-10):
         """(mean, var) of the latent f at xq, identical on every rank."""
-        lay, be, ld = self.lay, self.be, self.lay.nrows
+        t_start = time.perf_counter()
+        lay, be = self.lay, self.be
         xq = np.ascontiguousarray(xq, dtype=np.float64)
         m = xq.shape[0]
         mpad = round_up(m, 16)
@@ -371,36 +423,33 @@ class ShardedExactGP:
         w = be.zeros(mpad * lay.npad)
         if self.rank == 0:
             be.cross_fill(xq_dev, m, mpad, self.x_dev, self.n, self.d, lay.npad, w, lde)
-            be.sync()
         mean_p, var_p, tmp = be.zeros(mpad), be.zeros(mpad), be.zeros(mpad)
         ek = be.empty(mpad * lay.nb)
         for k in range(lay.npanels):
             owner, c0, nbk = lay.owner(k), lay.col0(k), lay.width(k)
             blk = w[c0 * lde : (c0 + nbk) * lde]
-            self._reduce(blk, owner)
+            if self.dist is not None:
+                be.reduce(self.dist, blk, owner)
             if self.rank == owner:
-                ek[: nbk * lde] = blk
-                be.after_comm()  # container copy (torch stream) must land before the engine's kernels read it
-                be.solve_panel(ek, lde, 0, mpad, self.store, ld, self.lcol0[k], c0, nbk, self.inv[k])
+                be.copy_into(ek[: nbk * lde], blk)
+                be.solve_panel(ek, 0, lde, mpad, self.store, self.poff[k], lay.ld(k), nbk, self.inv[k])
                 rest = lay.npad - (c0 + nbk)
                 if rest > 0:
-                    be.update_rows(w, lde, c0 + nbk, mpad, ek, lde, self.store, ld, self.lcol0[k], c0 + nbk, rest, nbk)
-                be.rowdot(ek, lde, mpad, nbk, self.z[c0 : c0 + nbk], tmp)
-                be.sync()
-                mean_p += tmp
-                be.after_comm()
-                be.rowdot(ek, lde, mpad, nbk, None, tmp)
-                be.sync()
-                var_p += tmp
-                be.after_comm()  # ... and the accumulations before `tmp` / `w` are touched again
-        self._allreduce(mean_p)
-        self._allreduce(var_p)
+                    be.update_rows(w, (c0 + nbk) * lde, lde, mpad, ek, lde, self.store, self.poff[k] + nbk, lay.ld(k), rest, nbk)
+                be.rowdot(ek, lde, mpad, nbk, self.z, c0, tmp)
+                be.add_into(mean_p, tmp)
+                be.rowdot(ek, lde, mpad, nbk, None, 0, tmp)
+                be.add_into(var_p, tmp)
+        if self.dist is not None:
+            be.allreduce(self.dist, mean_p)
+            be.allreduce(self.dist, var_p)
         mean = be.to_host(mean_p)[:m]
         var = be.to_host(be.var_finish(xq_dev, m, self.d, var_p, min_var))[:m]
+        self._times["predict_s"] = time.perf_counter() - t_start
         return mean, var
 
 
-def make_sharded_gp(kernel_id: int, hyp, nb: int = 512, backend_name: str | None = None):
+def make_sharded_gp(kernel_id: int, hyp, nb: int = 512, backend_name: str | None = None, local_rank: int | None = None):
     """Build a :class:`ShardedExactGP` for the calling process: rank/world from the launcher's
     environment (torch.distributed.run), one GPU per rank (LOCAL_RANK), RCCL communicator."""
     import torch
@@ -408,7 +457,8 @@ def make_sharded_gp(kernel_id: int, hyp, nb: int = 512, backend_name: str | None
     from . import parallel
     from .engine import ExactGPEngine
 
-    rank, world, local_rank = parallel.env_rank_world()
+    rank, world, env_local = parallel.env_rank_world()
+    local_rank = env_local if local_rank is None else local_rank
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = parallel.init(backend_name or "nccl", device=device)

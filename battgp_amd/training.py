@@ -98,19 +98,31 @@ def train_exact_gp_lbfgs(
     lr: float = 1,
     messages: bool = True,
 ) -> np.ndarray:
-    """L-BFGS with a strong-Wolfe line search (scipy's implementation) over the raw parameters,
-    one outer step per loop iteration as in ``training.py:147-164``."""
-    from scipy.optimize import minimize
+    """The reference's ``torch_lbfgs`` trainer (``training.py:108-171``) with the SAME optimiser object:
+    ``torch.optim.LBFGS(params, line_search_fn="strong_wolfe", lr=lr)`` - so up to 20 inner quasi-Newton iterations
+    per ``step`` (torch's default ``max_iter``), curvature history kept across the outer loop, ``lr`` honoured - driving
+    one flat fp64 tensor of raw parameters.  The closure does not back-propagate: loss and gradient of each
+    evaluation come from the GPU (``bgp_refit`` + ``bgp_lml_grad``) and are handed to torch as ``.grad``.  Outer loop,
+    loss history and the relative-change stop rule as in ``training.py:147-164``."""
+    import torch
 
     model.train()
     model.likelihood.train()
-    raw = model.raw_vector()
-    losses = np.zeros(max_iter + 1) * np.nan
-    loss = _loss(model, raw)
+    raw = torch.tensor(model.raw_vector(), dtype=torch.float64, requires_grad=True)
+    optimizer = torch.optim.LBFGS([raw], line_search_fn="strong_wolfe", lr=lr)
+
+    def closure():
+        optimizer.zero_grad()
+        value, grad = _loss_and_grad(model, raw.detach().numpy().copy())
+        raw.grad = torch.from_numpy(np.ascontiguousarray(grad, dtype=np.float64))
+        return torch.tensor(value, dtype=torch.float64)
+
+    loss = _loss(model, raw.detach().numpy().copy())
     if messages:
         print(f"start loss={loss * loss_scale}")
+    losses = np.zeros(max_iter + 1) * np.nan
     for i in range(max_iter):
-        loss = _loss(model, raw)
+        loss = _loss(model, raw.detach().numpy().copy())  # cached when the optimiser ended on this point
         current = loss * loss_scale
         losses[i] = current
         if i > 0:
@@ -118,28 +130,31 @@ def train_exact_gp_lbfgs(
             if abs((current - prev) / prev) < rel_ftol:
                 losses = losses[: i + 1]
                 break
-        res = minimize(
-            lambda r: _loss_and_grad(model, r), raw, jac=True, method="L-BFGS-B", options={"maxiter": 1, "maxls": 25}
-        )
-        raw = res.x
+        optimizer.step(closure)
+    # like the reference: the last recorded value is the loss of the LAST forward pass, before the final step
     losses[-1] = loss * loss_scale
     if messages:
         print(f"final loss={losses[-1]}")
-    model.set_raw_vector(raw)
+    model.set_raw_vector(raw.detach().numpy().copy())
     model.eval()
     model.likelihood.eval()
     return losses
 
 
+# options the reference hands to botorch's scipy L-BFGS-B (training.py:82-95); "eps" only matters for
+# finite-difference gradients and is unused with an analytic jacobian
+BOTORCH_SCIPY_OPTIONS = {"maxiter": 10000, "ftol": 1e-15, "gtol": 1e-15, "maxfun": 10000, "maxls": 10000}
+
+
 def train_exact_gp_botorch(model: BatteryCellGP, train_x=None, train_y=None, **_kwargs) -> float:
-    """``fit_gpytorch_mll`` is scipy L-BFGS-B on the raw parameters; returns the final loss
-    (``training.py:100-105``)."""
+    """``fit_gpytorch_mll`` = scipy L-BFGS-B on the raw parameters, with the reference's options; returns the final
+    loss ``-mll`` (``training.py:70-105``, which also prints it under the label "start loss")."""
     from scipy.optimize import minimize
 
     model.train()
     model.likelihood.train()
     res = minimize(
-        lambda r: _loss_and_grad(model, r), model.raw_vector(), jac=True, method="L-BFGS-B", options={"maxiter": 200}
+        lambda r: _loss_and_grad(model, r), model.raw_vector(), jac=True, method="L-BFGS-B", options=dict(BOTORCH_SCIPY_OPTIONS)
     )
     model.set_raw_vector(res.x)
     model.eval()

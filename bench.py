@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """bench.py - exact-GP fit+predict on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one synthetic cell: covariance fill over
-(time, I, SOC, T) inputs -> jittered blocked Cholesky -> z, alpha, LML -> cross fill,
-posterior mean and variance at M = 300 query points.  Inputs (X, y, Xq) are resident in HBM
-before the timed region starts; results stay on the device.
+A "step" is one pass of the hot path over one synthetic cell: covariance fill over (time, I, SOC, T) inputs ->
+jittered blocked Cholesky -> z, LML -> posterior mean and variance at M = 300 query points (the query rows ride
+through the factorisation).  Inputs (X, y, Xq) are resident in HBM before the timed region starts; results stay on
+the device.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 40000] [--kernel battgp]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 131072] [--kernel matern32]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU: every rank fits its OWN cell
-(the reference's "8-cell pack" = independent GPs, src/batt_models/battgp_full.py:41-60), no
-data-path collective; barrier + max-over-ranks timing; value = whole-job GFLOP/s.
-Prints ONE JSON line on rank 0.
+Headline workload (N = 1): BASELINE configs[2], the largest single-GPU configuration - full_gp, Matern-3/2 + noise,
+N = 131 072 - the size the north-star's kernel targets are quoted on.  configs[1] (N = 40 000, the reference kernel)
+rides along as `extra_configs`.
+
+N > 1 is launched by torch.distributed.run, one rank per GPU:
+  --mode cells   (default)  every rank fits its OWN cell (the reference's "8-cell pack" = independent GPs,
+                 src/batt_models/battgp_full.py:41-60); no data-path collective; weak scaling; value = whole-job GFLOP/s
+  --mode sharded ONE GP of size --n sharded over the ranks (column-panel block-cyclic Cholesky, RCCL broadcast of
+                 factored panels, battgp_amd/sharded.py; BASELINE configs[3]); strong scaling
+With --mode cells and N > 1 a `sharded` sub-record (one GP of --sharded-n points over all ranks) is appended so that a
+scaling run measures both multi-GPU paths.  Prints ONE JSON line on rank 0.
 """
 
 from __future__ import annotations
@@ -29,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak (= 256 CU x 2.4 GHz x 128 flop/clk)
 PEAK_HBM_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PROFILE_TAG = "r02"  # profiles/<tag>_n<N>_<kernel>_summary.json: committed rocprofv3 PMC passes of this round
 
 
 def algorithmic_flop(n: int, m: int) -> float:
@@ -36,52 +44,86 @@ def algorithmic_flop(n: int, m: int) -> float:
     return n**3 / 3.0 + float(n) * n * m + 2.0 * n * n
 
 
-def cpu_baseline(kernel_id, hyp, n_cpu: int, m: int, seed: int):
-    """Oracle (numpy fill + LAPACK dpotrf/dtrtrs) timed on the host cores: baseline only."""
+def kernel_setup(name: str):
+    from battgp_amd import KERNEL_BATTGP, KERNEL_MATERN32, synthetic
+
+    if name == "battgp":
+        return KERNEL_BATTGP, synthetic.HYP_BATTGP, "Wiener+ARD-RBF (reference full_gp kernel)"
+    return KERNEL_MATERN32, synthetic.HYP_MATERN32, "Matern-3/2 ARD + noise"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = port of the reference algorithm; checker code timed as a baseline, never the product)
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(kernel_name: str, n_cpu: int, m: int) -> dict:
+    """The oracle's dense algorithm on the host cores with its phases timed separately: threaded numpy fill,
+    LAPACK dpotrf (scipy), triangular solves + posterior.  `value` is the whole fit+predict; `potrf_gflops` is
+    LAPACK alone (what an honest "CPU Cholesky" figure means)."""
+    import scipy.linalg as sla
     from threadpoolctl import threadpool_info
 
     from battgp_amd import synthetic
-    from oracle.exact_gp import OracleGP
+    from oracle import kernels as K
 
-    x, y = synthetic.make_cell_data(n_cpu, seed=seed)
-    xq = synthetic.make_query(x, m)
-    t0 = time.perf_counter()
-    gp = OracleGP(kernel_id, hyp, x, y).fit()
-    gp.predict(xq)
-    dt = time.perf_counter() - t0
-    threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-    # BASELINE configs[0] (N = 2048, the reference's own CPU-runnable case) beside it
-    x0, y0 = synthetic.make_cell_data(2048, seed=2048)
-    xq0 = synthetic.make_query(x0, m)
-    t0 = time.perf_counter()
-    OracleGP(kernel_id, hyp, x0, y0).fit().predict(xq0)
-    dt0 = time.perf_counter() - t0
+    kid, hyp, _ = kernel_setup(kernel_name)
+
+    def run(n):
+        x, y = synthetic.make_cell_data(n, seed=n)
+        xq = synthetic.make_query(x, m)
+        t0 = time.perf_counter()
+        sigma = K.kernel_matrix_blocked(kid, hyp, x) if n > 2048 else K.kernel_matrix(kid, hyp, x)
+        sigma[np.diag_indices(n)] += K.noise(hyp)
+        t1 = time.perf_counter()
+        chol, info = sla.lapack.dpotrf(sigma, lower=1, clean=0, overwrite_a=1)
+        assert info == 0
+        t2 = time.perf_counter()
+        z = sla.solve_triangular(chol, y, lower=True, check_finite=False)
+        kxs = K.kernel_matrix(kid, hyp, x, xq)
+        v = sla.solve_triangular(chol, kxs, lower=True, check_finite=False)
+        mean = v.T @ z
+        var = K.kernel_diag(kid, hyp, xq) - np.einsum("ij,ij->j", v, v)
+        lml = -0.5 * float(z @ z) - float(np.sum(np.log(np.diag(chol)))) - 0.5 * n * np.log(2 * np.pi)
+        t3 = time.perf_counter()
+        return {
+            "n": n, "seconds": t3 - t0, "fill_s": t1 - t0, "potrf_s": t2 - t1, "solve_predict_s": t3 - t2,
+            "gflops": algorithmic_flop(n, m) / (t3 - t0) / 1e9, "potrf_gflops": (n**3 / 3.0) / (t2 - t1) / 1e9,
+            "lml": lml, "mean0": float(mean[0]), "var0": float(var[0]),
+        }
+
+    main = run(n_cpu)
+    cfg0 = run(2048)  # BASELINE configs[0]: the reference's own CPU-runnable case
+    blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
     return {
-        "config0_n2048": {"seconds": dt0, "value": algorithmic_flop(2048, m) / dt0 / 1e9},
-        "value": algorithmic_flop(n_cpu, m) / dt / 1e9,
+        "value": main["gflops"],
         "unit": "GFLOP/s",
-        "cores": int(threads),
+        "cores": int(blas_threads),
         "host_cpus": os.cpu_count(),
+        "fill_threads": min(32, os.cpu_count() or 1),
         "kind": "port",
-        "seconds": dt,
-        "sample": f"same workload at N={n_cpu} (one fit+predict, M={m}); numpy fill + LAPACK dpotrf/dtrtrs via scipy/OpenBLAS",
+        "seconds": main["seconds"],
+        "phases": {k: main[k] for k in ("fill_s", "potrf_s", "solve_predict_s")},
+        "potrf_gflops_lapack_alone": main["potrf_gflops"],
+        "config0_n2048": cfg0,
+        "sample": f"same workload ({kernel_name}) at N={n_cpu}, one fit+predict with M={m}: oracle algorithm = numpy fill on "
+                  f"{min(32, os.cpu_count() or 1)} threads + LAPACK dpotrf/dtrtrs (scipy/OpenBLAS, {blas_threads} BLAS threads)",
     }
 
 
-def traffic_from_profile(n: int, kernel: str, key: str = "hbm_bytes_per_dispatch"):
-    """Per-dispatch HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) or PMC MFMA utilisation of the trailing-update
-    kernel from the committed rocprofv3 passes (tools/profile_round.sh -> profiles/*_summary.json, which
-    holds the calibration); None for workloads that were not profiled."""
-    path = os.path.join(ROOT, "profiles", f"r01_n{n}_summary.json")
-    if kernel != "battgp" or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)["gemm_nt_128x128"].get(key)
+# ---------------------------------------------------------------------------------------------------------------
+# committed profile evidence (rocprofv3 PMC passes can not run inside the bench)
+# ---------------------------------------------------------------------------------------------------------------
+def profile_summary(n: int, kernel: str):
+    for tag in (PROFILE_TAG, "r01"):
+        for name in (f"{tag}_n{n}_{kernel}_summary.json", f"{tag}_n{n}_summary.json" if kernel == "battgp" else None):
+            if name and os.path.exists(os.path.join(ROOT, "profiles", name)):
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    return json.load(f), name
+    return None, None
 
 
 def n_max_from_profile():
-    """Largest N measured on one MI355X (column-slab layout of the factor, tools/large_n.py): the committed
-    record, not re-measured here (one fit at that size takes ~100 s)."""
+    """Largest N measured on one MI355X (column-slab layout of the factor, tools/large_n.py): the committed record,
+    not re-measured here (one fit at that size takes ~100 s)."""
     path = os.path.join(ROOT, "profiles", "r01_large_n.json")
     if not os.path.exists(path):
         return None
@@ -95,92 +137,302 @@ def n_max_from_profile():
     }
 
 
-def target_size_report(n: int, m: int) -> dict:
-    """One fit+predict per kernel at the size the north-star targets are quoted on (N = 131 072):
-    fill GB/s vs 8 TB/s, trailing-update TFLOP/s vs 78.6, and on-device residuals as correctness
-    evidence where no CPU oracle can follow.  Not part of `value`."""
+# ---------------------------------------------------------------------------------------------------------------
+# one workload on this rank's GPU
+# ---------------------------------------------------------------------------------------------------------------
+class CellWorkload:
+    def __init__(self, n, m, kernel, device_index, seed, args):
+        import torch
+
+        from battgp_amd import synthetic
+        from battgp_amd.engine import ExactGPEngine
+
+        self.torch, self.n, self.m = torch, n, m
+        kid, hyp, _ = kernel_setup(kernel)
+        x, y = synthetic.make_cell_data(n, seed=seed)
+        xq = synthetic.make_query(x, m)
+        dev = torch.device("cuda", device_index)
+        self.tx, self.ty, self.txq = (torch.from_numpy(a).to(dev) for a in (x, y, xq))
+        self.tmean = torch.empty(m, dtype=torch.float64, device=dev)
+        self.tvar = torch.empty(m, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        self.eng = ExactGPEngine(kid, hyp, device=device_index)
+        if args.nb > 0:
+            self.eng.set_options(nb_outer=args.nb)
+        if args.lookahead >= 0:
+            self.eng.set_options(lookahead=args.lookahead)
+        if args.panel_scheme >= 0:
+            self.eng.set_panel_scheme(args.panel_scheme)
+        if args.slab != 0:
+            self.eng.set_layout(args.slab)
+        self.separate = args.separate
+
+    def step(self):
+        e = self.eng
+        if self.separate:
+            e.fit_device(self.tx.data_ptr(), self.ty.data_ptr(), self.n, 4)
+            e.predict_device(self.txq.data_ptr(), self.m, self.tmean.data_ptr(), self.tvar.data_ptr(), 1e-10)
+        else:  # the reference's flow: the first predict triggers the factorisation; one fused pass
+            e.fit_predict_device(self.tx.data_ptr(), self.ty.data_ptr(), self.n, 4, self.txq.data_ptr(), self.m,
+                                 self.tmean.data_ptr(), self.tvar.data_ptr(), 1e-10)
+
+    def fill_steady_gbs(self, reps=8):
+        """The fill kernel launched back to back on the factor's own footprint-sized scratch (its steady rate: no
+        clock ramp after a host-side gap - tools/fill_gap_probe.py)."""
+        torch, n = self.torch, self.n
+        free_b, _ = torch.cuda.mem_get_info()
+        ld = n + 384
+        if free_b < ld * n * 8 + (4 << 30):
+            return None
+        scratch = torch.empty((n, ld), dtype=torch.float64, device=self.tx.device)
+        torch.cuda.synchronize()
+        rates = []
+        for _ in range(reps):
+            self.eng.fill_device(self.tx.data_ptr(), n, self.tx.data_ptr(), n, 4, scratch.data_ptr(), ld, lower=1, diag_add=float(self.eng.hyp[0]))
+            ph = self.eng.phase_times()
+            rates.append(ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9)
+        del scratch
+        torch.cuda.empty_cache()
+        return float(np.median(rates[reps // 2:]))
+
+    def memset_gbs(self, reps=4):
+        """hipMemset of the same number of bytes: the write-stream ceiling of this GPU as a library call sees it."""
+        torch, n = self.torch, self.n
+        nbytes = 4 * n * (n + 1)
+        free_b, _ = torch.cuda.mem_get_info()
+        if free_b < nbytes + (4 << 30):
+            return None
+        buf = torch.empty(nbytes // 8, dtype=torch.float64, device=self.tx.device)
+        torch.cuda.synchronize()
+        rates = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            buf.zero_()
+            b.record()
+            b.synchronize()
+            rates.append(nbytes / (a.elapsed_time(b) * 1e-3) / 1e9)
+        del buf
+        torch.cuda.empty_cache()
+        return float(np.median(rates[1:]))
+
+    def close(self):
+        self.eng.close()
+
+
+def summarise(phases, n, m, kernel, desc):
+    """Roofline records from the HIP-event phase timers of the timed steps (events on the launching streams,
+    inside the library)."""
+    avg = {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
+    trail_tflops = avg["trail_flop"] / (avg["trail_ms"] * 1e-3) / 1e12 if avg["trail_ms"] > 0 else 0.0
+    union = avg.get("trail_union_ms", 0.0)
+    fill_gbs = avg["fill_bytes"] / (avg["fill_ms"] * 1e-3) / 1e9 if avg["fill_ms"] > 0 else 0.0
+    potrf_tflops = (n**3 / 3.0) / (avg["potrf_ms"] * 1e-3) / 1e12 if avg["potrf_ms"] > 0 else 0.0
+    prof, prof_name = profile_summary(n, kernel)
+    gem = (prof or {}).get("gemm_nt_128x128", {})
+    launches = int(round(avg["trail_launches"]))
+    roofline = {
+        "bound": "mfma",
+        "kernel": "gemm_nt_kernel<128,128,2> (rank-NB SYRK trailing update of the blocked Cholesky)",
+        "achieved": trail_tflops,
+        "peak": PEAK_FP64_MFMA_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": trail_tflops / PEAK_FP64_MFMA_TFLOPS,
+        "launches_per_step": launches,
+        "flop_per_launch": avg["trail_flop"] / max(1, launches),
+        "avg_launch_ms": avg["trail_ms"] / max(1, launches),
+        "achieved_while_running": (avg["trail_flop"] / (union * 1e-3) / 1e12) if union > 0 else None,
+        "frac_while_running": (avg["trail_flop"] / (union * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if union > 0 else None,
+        "traffic": gem.get("hbm_bytes_per_dispatch"),
+        "traffic_source": f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; not re-collected by this run)" if gem else None,
+        "mfma_util_pmc": gem.get("mfma_util"),
+        "note": "achieved = sum of algorithmic flop 2k*#{i>=j} of the outer trailing-update launches / sum of their HIP-event "
+                "durations (= flop per launch / average launch duration); with look-ahead the la(k) and rest(k) launches overlap "
+                "on two streams, so achieved_while_running divides the same flop by the UNION of the launch intervals",
+    }
+    roofline_fill = {
+        "bound": "hbm",
+        "kernel": "fill_kernel (lower triangle, 4N(N+1) algorithmic bytes per fit)",
+        "achieved": fill_gbs,
+        "peak": PEAK_HBM_GBS,
+        "unit": "GB/s",
+        "frac": fill_gbs / PEAK_HBM_GBS,
+        "fill_ms": avg["fill_ms"],
+        "traffic": (prof or {}).get("fill_kernel", {}).get("hbm_bytes_per_dispatch"),
+        "note": "in situ: the fill launches of the timed steps, HIP events around them inside the fit",
+    }
+    return {
+        "workload": f"full_gp, {desc}, N={n} synthetic 4-D inputs, M={m} queries",
+        "roofline": roofline,
+        "roofline_fill": roofline_fill,
+        "phases_ms": {k: avg[k] for k in ("h2d_ms", "fill_ms", "potrf_ms", "solve_ms", "cross_ms", "var_ms", "d2h_ms", "trail_ms")},
+        "potrf_tflops": potrf_tflops,
+        "potrf_frac_of_peak": potrf_tflops / PEAK_FP64_MFMA_TFLOPS,
+    }
+
+
+def run_cells(args, rank, world, local_rank, dist, red_dev):
     import torch
 
-    from battgp_amd import KERNEL_BATTGP, KERNEL_MATERN32, synthetic
-    from battgp_amd.engine import EngineError, ExactGPEngine
+    from battgp_amd import parallel
 
+    n, m = args.n, args.m
+    _, _, desc = kernel_setup(args.kernel)
+    # every rank = a different cell (different seed), same size: weak scaling, no collective
+    wl = CellWorkload(n, m, args.kernel, local_rank, n + rank, args)
+
+    def barrier():
+        parallel.barrier(dist)
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    phases = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()  # every C-ABI call returns only after its own stream has drained
+        phases.append(wl.eng.phase_times())
+    barrier()
+    elapsed = parallel.max_over_ranks(dist, time.perf_counter() - t0, device=red_dev)
+
+    resid = None if args.no_residuals else wl.eng.residuals(256)  # on-device evidence at the benchmarked size
+    mean_host = wl.tmean.cpu().numpy()
+    lml, jitter, mem_bytes = wl.eng.lml, wl.eng.jitter, wl.eng.device_bytes()
+    out = None
+    if rank == 0:
+        flop = algorithmic_flop(n, m)
+        rec = summarise(phases, n, m, args.kernel, desc)
+        out = {
+            "metric": "exact-GP fit+predict throughput (fp64)",
+            "value": world * flop * args.steps / elapsed / 1e9,
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": rec["workload"] + ", one cell per GPU",
+                "n": n, "m": m, "kernel": args.kernel, "flop_per_step": flop,
+                "parallelism": f"{world} independent cells" if world > 1 else "1 cell",
+            },
+            "roofline": rec["roofline"],
+            "roofline_fill": rec["roofline_fill"],
+            "phases_ms": rec["phases_ms"],
+            "potrf_tflops": rec["potrf_tflops"],
+            "potrf_frac_of_peak": rec["potrf_frac_of_peak"],
+            "lml": lml,
+            "jitter": jitter,
+            "residuals": {"rel_solve": resid[0], "max_llt": resid[1]} if resid else None,
+            "mean_first": [float(v) for v in mean_host[:3]],
+            "device_bytes": mem_bytes,
+            "n_max_per_gpu": n_max_from_profile(),
+        }
+    wl.eng.close()  # frees (or parks) the factor before the scratch-sized side measurements
+    if rank == 0 and world == 1 and not args.no_extras:
+        # steady rate of the fill kernel and the memset ceiling, beside the in-situ figure
+        wl2 = CellWorkload(n, m, args.kernel, local_rank, n, args)
+        from battgp_amd.engine import trim_pool
+
+        trim_pool(local_rank)
+        out["roofline_fill"]["steady_gbs"] = wl2.fill_steady_gbs()
+        out["roofline_fill"]["steady_frac"] = (out["roofline_fill"]["steady_gbs"] or 0.0) / PEAK_HBM_GBS
+        out["roofline_fill"]["hipmemset_same_bytes_gbs"] = wl2.memset_gbs()
+        wl2.close()
+        trim_pool(local_rank)
+        extras = []
+        for en, ek in ((40000, "battgp"),):
+            if en == n and ek == args.kernel:
+                continue
+            w = CellWorkload(en, m, ek, local_rank, en, args)
+            w.step()
+            ph, t0 = [], time.perf_counter()
+            for _ in range(3):
+                w.step()
+                ph.append(w.eng.phase_times())
+            dt = (time.perf_counter() - t0) / 3
+            rec = summarise(ph, en, m, ek, kernel_setup(ek)[2])
+            res = w.eng.residuals(256)
+            rec.update({"ms_per_step": dt * 1e3, "gflops": algorithmic_flop(en, m) / dt / 1e9, "lml": w.eng.lml,
+                        "residuals": {"rel_solve": res[0], "max_llt": res[1]}})
+            extras.append(rec)
+            w.close()
+        out["extra_configs"] = extras
+    return out
+
+
+def run_sharded(args, rank, world, local_rank, n):
+    """ONE exact GP of n points over all ranks (BASELINE configs[3]); returns the record on rank 0."""
+    import torch
+
+    from battgp_amd import parallel, synthetic
+    from battgp_amd.sharded import make_sharded_gp
+
+    kid, hyp, desc = kernel_setup(args.kernel)
+    gp = make_sharded_gp(kid, hyp, nb=args.sharded_nb, backend_name=args.backend, local_rank=local_rank)
     x, y = synthetic.make_cell_data(n)
-    xq = synthetic.make_query(x, m)
-    rep = {"n": n}
-    for name, kid, hyp in (("battgp", KERNEL_BATTGP, synthetic.HYP_BATTGP), ("matern32", KERNEL_MATERN32, synthetic.HYP_MATERN32)):
-        eng = ExactGPEngine(kid, hyp, device=torch.cuda.current_device())
-        try:
-            # fill kernel alone, launched back to back on a scratch matrix of the same shape: its steady
-            # rate.  (Inside a fit the fill is the first big kernel after a host-side gap and pays ~2 ms of
-            # clock ramp-up - tools/fill_hot_probe.py - which is reported separately as fill_gbs.)
-            ld = n + 384
-            scratch = torch.empty((n, ld), dtype=torch.float64, device="cuda")
-            tx = torch.from_numpy(x).cuda()
-            torch.cuda.synchronize()
-            rates = []
-            for _ in range(8):
-                eng.fill_device(tx.data_ptr(), n, tx.data_ptr(), n, 4, scratch.data_ptr(), ld, lower=1, diag_add=float(hyp[0]))
-                ph = eng.phase_times()
-                rates.append(ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9)
-            del scratch, tx
-            torch.cuda.empty_cache()
-            fill_steady = float(np.median(rates[4:]))  # the first launches still see the clocks ramp up
-            eng.fit_predict(x, y, xq)  # first pass from an idle, down-clocked GPU: warm-up only
-            t0 = time.perf_counter()
-            eng.fit_predict(x, y, xq)  # fill + factorisation with the query rows riding + posterior
-            wall = time.perf_counter() - t0
-            ph = eng.phase_times()
-            res = eng.residuals(256)
-            rep[name] = {
-                "fit_predict_s": wall,
-                "fill_gbs": ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9,
-                "fill_frac_hbm": ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "fill_steady_gbs": fill_steady,
-                "fill_steady_frac_hbm": fill_steady / PEAK_HBM_GBS,
-                "potrf_tflops": (n**3 / 3.0) / (ph["potrf_ms"] * 1e-3) / 1e12,
-                "trail_tflops": ph["trail_flop"] / (ph["trail_ms"] * 1e-3) / 1e12,
-                "trail_frac_mfma": ph["trail_flop"] / (ph["trail_ms"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
-                "phases_ms": {k: ph[k] for k in ("fill_ms", "potrf_ms", "solve_ms", "cross_ms", "var_ms", "trail_ms")},
-                "lml": eng.lml,
-                "jitter": eng.jitter,
-                "residuals": {"rel_solve": res[0], "max_llt": res[1]},
-                "device_bytes": eng.device_bytes(),
-            }
-        except EngineError as exc:  # e.g. not enough HBM on a smaller part
-            rep[name] = {"error": str(exc)}
-        finally:
-            eng.close()
-    return rep
+    xq = synthetic.make_query(x, args.m)
+    steps = max(1, args.sharded_steps)
+    gp.fit(x, y)  # warm-up: allocations, RCCL channel set-up, clocks
+    gp.predict(xq)
+    parallel.barrier(gp.dist)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lml = gp.fit(x, y)
+        mean, var = gp.predict(xq)
+    parallel.barrier(gp.dist)
+    torch.cuda.synchronize()
+    dt = parallel.max_over_ranks(gp.dist, time.perf_counter() - t0, device=gp.be.device if args.backend == "nccl" else "cpu") / steps
+    rec = None
+    if rank == 0:
+        flop = algorithmic_flop(n, args.m)
+        rec = {
+            "workload": f"full_gp, {desc}, ONE GP of N={n} sharded over {world} GPU(s): column-panel block-cyclic Cholesky, "
+                        f"nb={args.sharded_nb}, RCCL broadcast of factored panels",
+            "n": n, "world": world, "steps": steps, "s_per_fit_predict": dt, "gflops": flop / dt / 1e9,
+            "gflops_per_gpu": flop / dt / 1e9 / world, "frac_of_mfma_peak_per_gpu": flop / dt / 1e12 / world / PEAK_FP64_MFMA_TFLOPS,
+            "timers_s": gp.timers(), "lml": lml, "jitter": gp.jitter, "mean_first": [float(v) for v in mean[:3]],
+            "var_first": [float(v) for v in var[:3]], "scaling": "strong",
+        }
+    gp.close()
+    return rec
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", "--size", dest="n", type=int, default=40000,
-                    help="training points per cell (configs[1]: 40 000); use --size under torch.distributed.run, whose argparse rejects --n as an ambiguous prefix of its own options")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=131072,
+                    help="training points per cell (configs[2]: 131 072); use --size under torch.distributed.run, whose argparse "
+                         "rejects --n as an ambiguous prefix of its own options")
     ap.add_argument("--m", type=int, default=300, help="query points (battgp_full.py:98)")
-    ap.add_argument("--kernel", default="battgp", choices=["battgp", "matern32"])
+    ap.add_argument("--kernel", default="matern32", choices=["battgp", "matern32"])
+    ap.add_argument("--mode", default="cells", choices=["cells", "sharded"])
     ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
     ap.add_argument("--lookahead", type=int, default=-1, help="bits 0-2: look-ahead depth (0 off, 1 default); +8: panel-stream updates ordered before rest(k); +16: no atomic epilogue")
     ap.add_argument("--panel-scheme", type=int, default=-1, help="0 = 64-wide chain over all rows, 1 = diagonal-block chain + one deep TRSM GEMM (default)")
     ap.add_argument("--slab", type=int, default=0, help="bgp_set_layout: 0 automatic, -1 full square, > 0 column-slab width")
-    ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-n", type=int, default=16384, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (steady fill, memset ceiling, N = 40 000 extra config)")
     ap.add_argument("--separate", action="store_true", help="bgp_fit then bgp_predict (separate triangular-solve pass) instead of the fused call")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1: nccl (= RCCL, the driver's runs); gloo with --share-gpu rehearses "
                          "the multi-rank path on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (rehearsal of the N > 1 path on one GPU)")
-    ap.add_argument("--target-n", type=int, default=131072,
-                    help="also report the kernels' roofline fractions at the north-star size (1 GPU only; 0 = skip)")
+    ap.add_argument("--sharded-n", type=int, default=98304, help="size of the ONE sharded GP appended to a multi-GPU cells run (0 = skip)")
+    ap.add_argument("--sharded-nb", type=int, default=1024)
+    ap.add_argument("--sharded-steps", type=int, default=1)
     args = ap.parse_args()
 
     import torch
-
-    from battgp_amd import KERNEL_BATTGP, KERNEL_MATERN32, synthetic
-    from battgp_amd.engine import ExactGPEngine
 
     from battgp_amd import parallel
 
@@ -195,152 +447,32 @@ def main() -> None:
     dist = parallel.init(args.backend, device=torch.device("cuda", local_rank))  # nccl = RCCL; None for 1 process
     red_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
-    kernel_id, hyp = (
-        (KERNEL_BATTGP, synthetic.HYP_BATTGP) if args.kernel == "battgp" else (KERNEL_MATERN32, synthetic.HYP_MATERN32)
-    )
-    n, m = args.n, args.m
-    # every rank = a different cell (different seed), same size: weak scaling, no collective
-    x, y = synthetic.make_cell_data(n, seed=n + rank)
-    xq = synthetic.make_query(x, m)
-    dev = torch.device("cuda", local_rank)
-    tx = torch.from_numpy(x).to(dev)
-    ty = torch.from_numpy(y).to(dev)
-    txq = torch.from_numpy(xq).to(dev)
-    tmean = torch.empty(m, dtype=torch.float64, device=dev)
-    tvar = torch.empty(m, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
-
-    eng = ExactGPEngine(kernel_id, hyp, device=local_rank)
-    if args.nb > 0:
-        eng.set_options(nb_outer=args.nb)
-    if args.lookahead >= 0:
-        eng.set_options(lookahead=args.lookahead)
-    if args.panel_scheme >= 0:
-        eng.set_panel_scheme(args.panel_scheme)
-    if args.slab != 0:
-        eng.set_layout(args.slab)
-
-    def step():
-        if args.separate:
-            eng.fit_device(tx.data_ptr(), ty.data_ptr(), n, 4)
-            eng.predict_device(txq.data_ptr(), m, tmean.data_ptr(), tvar.data_ptr(), 1e-10)
-        else:  # the reference's flow: the first predict triggers the factorisation; one fused pass
-            eng.fit_predict_device(tx.data_ptr(), ty.data_ptr(), n, 4, txq.data_ptr(), m, tmean.data_ptr(), tvar.data_ptr(), 1e-10)
-
-    def barrier():
-        parallel.barrier(dist)
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    phases = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()  # every C-ABI call returns only after its own stream has drained
-        phases.append(eng.phase_times())
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(dist, elapsed, device=red_dev)
-
-    # The la(k) and rest(k) launches of a panel overlap each other in the default schedule (fastest wall
-    # clock), which stretches both event-timed durations.  One extra, untimed step with la(k) ordered before
-    # rest(k) (lookahead = 1 | 8, ~1 % slower overall) gives the kernel's own rate per launch.
-    serial = None
-    if args.lookahead < 0:
-        eng.set_options(lookahead=1 | 8)
-        step()
-        ph2 = eng.phase_times()
-        serial = ph2["trail_flop"] / (ph2["trail_ms"] * 1e-3) / 1e12 if ph2["trail_ms"] > 0 else None
-        eng.set_options(lookahead=1)
-
-    resid = None
-    if not args.no_residuals:
-        resid = eng.residuals(256)  # on-device correctness evidence at the benchmarked size
-    mean_host = tmean.cpu().numpy()
-    lml, jitter = eng.lml, eng.jitter
-    mem_bytes = eng.device_bytes()
-    eng.close()
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        flop = algorithmic_flop(n, m)
-        value = world * flop * args.steps / elapsed / 1e9
-        avg = {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
-        trail_tflops = avg["trail_flop"] / (avg["trail_ms"] * 1e-3) / 1e12 if avg["trail_ms"] > 0 else 0.0
-        fill_gbs = avg["fill_bytes"] / (avg["fill_ms"] * 1e-3) / 1e9 if avg["fill_ms"] > 0 else 0.0
-        potrf_tflops = (n**3 / 3.0) / (avg["potrf_ms"] * 1e-3) / 1e12 if avg["potrf_ms"] > 0 else 0.0
-        out = {
-            "metric": "exact-GP fit+predict throughput (fp64)",
-            "value": value,
-            "unit": "GFLOP/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"full_gp, {'Wiener+ARD-RBF (reference full_gp kernel)' if args.kernel == 'battgp' else 'Matern-3/2 ARD'}, "
-                f"N={n} synthetic 4-D inputs, M={m} queries, one cell per GPU",
-                "n": n,
-                "m": m,
-                "kernel": args.kernel,
-                "flop_per_step": flop,
-                "parallelism": f"{world} independent cells" if world > 1 else "1 cell",
-            },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "gemm_nt_kernel<128,128,2> (rank-NB SYRK trailing update of the blocked Cholesky)",
-                "achieved": trail_tflops,
-                "peak": PEAK_FP64_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": trail_tflops / PEAK_FP64_MFMA_TFLOPS,
-                "achieved_while_running": (avg["trail_flop"] / (avg["trail_union_ms"] * 1e-3) / 1e12) if avg.get("trail_union_ms", 0) > 0 else None,
-                "frac_while_running": (avg["trail_flop"] / (avg["trail_union_ms"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if avg.get("trail_union_ms", 0) > 0 else None,
-                "achieved_non_overlapped": serial,
-                "frac_non_overlapped": (serial / PEAK_FP64_MFMA_TFLOPS) if serial else None,
-                "traffic": traffic_from_profile(n, args.kernel),
-                "launches_per_step": None,
-                "mfma_util_pmc": traffic_from_profile(n, args.kernel, "mfma_util"),
-                "note": "sum of algorithmic flop m(m+1)k of the outer trailing updates / sum of their HIP-event durations "
-                        "(= flop per launch / average launch duration); with look-ahead the la and rest launches of a panel "
-                        "overlap each other and the next panel's factorisation, so this under-states the kernel "
-                        "(achieved_while_running: the same flop over the UNION of the launch intervals of the timed steps, i.e. the rate "
-                        "while at least one trailing update is running; achieved_non_overlapped: the same launches in one extra "
-                        "untimed step with la(k) ordered before rest(k)); "
-                        "mfma_util_pmc is SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) of the same kernel "
-                        "from the serialised counter pass in profiles/",
-            },
-            "roofline_fill": {
-                "bound": "hbm",
-                "kernel": "fill_kernel (lower triangle, 4N(N+1) algorithmic bytes)",
-                "achieved": fill_gbs,
-                "peak": PEAK_HBM_GBS,
-                "unit": "GB/s",
-                "frac": fill_gbs / PEAK_HBM_GBS,
-            },
-            "phases_ms": {k: avg[k] for k in ("h2d_ms", "fill_ms", "potrf_ms", "solve_ms", "cross_ms", "var_ms", "d2h_ms", "trail_ms")},
-            "potrf_tflops": potrf_tflops,
-            "potrf_frac_of_peak": potrf_tflops / PEAK_FP64_MFMA_TFLOPS,
-            "lml": lml,
-            "jitter": jitter,
-            "residuals": {"rel_solve": resid[0], "max_llt": resid[1]} if resid else None,
-            "mean_first": [float(v) for v in mean_host[:3]],
-            "device_bytes": mem_bytes,
-            "n_max_per_gpu": n_max_from_profile(),
-        }
-        out["roofline"]["launches_per_step"] = int(round(avg["trail_launches"]))
-        if world == 1 and args.target_n > 0 and args.target_n != n:
-            out["target_size"] = target_size_report(args.target_n, m)
-        if args.cpu_n > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(kernel_id, hyp, args.cpu_n, m, seed=args.cpu_n)
-        elif world > 1:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+    if args.mode == "sharded":
+        rec = run_sharded(args, rank, world, local_rank, args.n)
+        if rank == 0:
+            flop = algorithmic_flop(args.n, args.m)
+            out = {
+                "metric": "exact-GP fit+predict throughput (fp64)", "value": rec["gflops"], "unit": "GFLOP/s", "n_gpus": world,
+                "steps": rec["steps"], "warmup": 1, "ms_per_step": rec["s_per_fit_predict"] * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": rec["workload"], "n": args.n, "m": args.m, "kernel": args.kernel, "flop_per_step": flop,
+                           "parallelism": f"1 GP sharded over {world} GPU(s)"},
+                "sharded": rec,
+            }
+            print(json.dumps(out), flush=True)
+    else:
+        out = run_cells(args, rank, world, local_rank, dist, red_dev)
+        sh = None
+        if world > 1 and args.sharded_n > 0:
+            sh = run_sharded(args, rank, world, local_rank, args.sharded_n)
+        if rank == 0:
+            if sh is not None:
+                out["sharded"] = sh
+            if args.cpu_n > 0 and world == 1:
+                out["cpu_baseline"] = cpu_baseline(args.kernel, args.cpu_n, args.m)
+            elif world > 1:
+                out["cpu_baseline"] = None
+            print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

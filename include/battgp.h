@@ -258,6 +258,27 @@ int bgp_factor_panel_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t n
 int bgp_factor_pack_panel_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t nrows, int nbk, double* inv_dev,
                               double* pack_dev, int* info_out);
 
+/* The asynchronous form used by the sharded driver: nothing is read back, the call only enqueues.  The handle's
+ * device-side failure flag is NOT reset (bgp_flag_reset_dev does that once per factorisation attempt): a failed pivot -
+ * reported as gofs + the 1-based index within the panel - turns every later kernel of this handle's pipeline into a
+ * no-op.  After the panel the flag is copied into the 8-byte slot flag_slot_dev (the element behind the packed panel:
+ * it travels with the broadcast), as an int in the low word. */
+int bgp_factor_pack_panel_async_dev(bgp_handle* h, double* panel_dev, int64_t ld, int64_t nrows, int nbk, double* inv_dev,
+                                    double* pack_dev, int64_t gofs, double* flag_slot_dev);
+
+/* Failure flag of the handle's pipeline (sharded driver): reset it (asynchronous); merge a received panel's flag slot
+ * into it (asynchronous: if the slot is non-zero and the flag is still clear, the flag takes its value); read it
+ * (synchronous: drains the handle's streams). */
+int bgp_flag_reset_dev(bgp_handle* h);
+int bgp_flag_merge_dev(bgp_handle* h, const double* flag_slot_dev);
+int bgp_flag_read(bgp_handle* h, int* flag_out);
+
+/* The HIP stream the handle's asynchronous calls are enqueued on (which = 0: main, 1: auxiliary), as a hipStream_t.
+ * A host framework that moves data for the engine (torch.distributed / RCCL in battgp_amd/sharded.py) wraps it
+ * (torch.cuda.ExternalStream) so that its copies and collectives are ORDERED with the engine's kernels by the
+ * stream itself - no host synchronisation between a broadcast and the kernels that produce / consume its buffer. */
+void* bgp_get_stream(bgp_handle* h, int which);
+
 /* E_K <- E_K L_KK^-T for a row block E_K[me, nbk] against a factored panel's diagonal block. */
 int bgp_solve_panel_dev(bgp_handle* h, double* E_dev, int64_t lde, int64_t me, const double* Lkk_dev,
                         int64_t ld, int nbk, const double* inv_dev);
@@ -268,12 +289,14 @@ int bgp_gemm_nt_sub_async_dev(bgp_handle* h, double* C_dev, int64_t ldc, const d
 
 /* All rank-k updates of one step of the sharded factorisation in one call: for i < count
  *   C_i[rows_i, ncols_i] -= P[p_off_i .. , 0..k) P[p_off_i .. p_off_i + ncols_i, 0..k)^T    (lower trapezoid)
- * with C_i = store_dev + desc[4 i], rows_i = desc[4 i + 1], ncols_i = desc[4 i + 2], p_off_i = desc[4 i + 3]
- * (desc on the host).  The launches alternate between the engine's two streams, so that the partial last
- * round of workgroups of one panel's update overlaps the next panel's; deep updates (k >= 256) accumulate
- * through L2 atomics like the single-GPU trailing update.  Asynchronous (bgp_sync). */
-int bgp_update_panels_dev(bgp_handle* h, double* store_dev, int64_t ld, const int64_t* desc, int count,
-                          const double* P_dev, int64_t ldp, int k);
+ * with C_i = store_dev + desc[5 i] (leading dimension desc[5 i + 4]), rows_i = desc[5 i + 1], ncols_i = desc[5 i + 2],
+ * p_off_i = desc[5 i + 3] (desc on the host): every local panel keeps only the rows from its own diagonal down, so
+ * each has its own leading dimension.  The launches alternate between the engine's two streams, so that the
+ * partial last round of workgroups of one panel's update overlaps the next panel's; deep updates (k >= 256)
+ * accumulate through L2 atomics like the single-GPU trailing update.  abort_flag_dev (may be NULL): an 8-byte flag slot
+ * (see bgp_factor_pack_panel_async_dev) - non-zero turns the launches into no-ops.  Asynchronous (bgp_sync). */
+int bgp_update_panels_dev(bgp_handle* h, double* store_dev, const int64_t* desc, int count, const double* P_dev,
+                          int64_t ldp, int k, const double* abort_flag_dev);
 
 /* out_host[0] = sum_{i<n} log A[i + i*ld] (half log-determinant of a factored diagonal block). Synchronous. */
 int bgp_diag_logsum_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t n, double* out_host);
@@ -287,6 +310,12 @@ int bgp_rowdot_dev(bgp_handle* h, const double* E_dev, int64_t lde, int64_t M, i
  * (K0: s_w t^3/3 + s_r, the diag branch of src/gp/wiener_kernel.py:15-16). */
 int bgp_var_finish_dev(bgp_handle* h, const double* Xq_dev, int64_t M, int D, const double* ssq_dev, double min_var,
                        double* out_dev);
+
+/* Diagnostic: one wavefront on the handle's AUXILIARY stream records nsamp pairs (wall clock [100 MHz ticks],
+ * shader clock [cycles]) into out_dev[2 * nsamp] (uint64), spinning `spin` FMAs between samples - launched next to
+ * work on the main stream it shows the shader clock the SMU grants WHILE that work runs (tools/fill_gap_probe.py).
+ * Asynchronous (bgp_sync). */
+int bgp_debug_clock_samples_dev(bgp_handle* h, uint64_t* out_dev, int nsamp, int spin);
 
 /* Wait for everything enqueued on the handle's streams. */
 int bgp_sync(bgp_handle* h);

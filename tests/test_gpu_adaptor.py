@@ -327,3 +327,166 @@ def test_handle_pool_is_thread_safe():
         t.join()
     assert not errors, errors
     trim_pool()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: trainers against torch autograd, residency of the training data, n_devices, Wiener wrapper
+# ---------------------------------------------------------------------------------------------
+def _torch_autograd_model(x, y, hyp0, ranges):
+    """The reference's model restated in torch fp64 WITH autograd (CPU): raw parameters under the same constraints
+    (sigmoid on the three Interval ranges, softplus on the lengthscales - cell_gp.py:182-194 quirk), Wiener + ARD-RBF
+    kernel by direct differences, loss = -log_prob / N through torch.linalg.cholesky.  Checker only."""
+    xt, yt = torch.as_tensor(x), torch.as_tensor(y)
+    n = len(y)
+
+    def inv_sig(v, lo, hi):
+        p = (v - lo) / (hi - lo)
+        return np.log(p) - np.log1p(-p)
+
+    raw0 = np.concatenate(([inv_sig(hyp0[i], *ranges[i]) for i in range(3)], [v + np.log(-np.expm1(-v)) for v in hyp0[3:]]))
+    raw = torch.tensor(raw0, dtype=torch.float64, requires_grad=True)
+    lo = torch.tensor([r[0] for r in ranges], dtype=torch.float64)
+    hi = torch.tensor([r[1] for r in ranges], dtype=torch.float64)
+
+    def loss_fn():
+        head = lo + (hi - lo) * torch.sigmoid(raw[:3])
+        ls = torch.nn.functional.softplus(raw[3:])
+        t = xt[:, :1]
+        mn = torch.minimum(t, t.T)
+        wien = mn**3 / 3 + (t - t.T).abs() * mn**2 / 2
+        z = xt[:, 1:] / ls
+        sq = ((z[:, None, :] - z[None, :, :]) ** 2).sum(-1)
+        sigma = head[1] * wien + head[2] * torch.exp(-0.5 * sq) + head[0] * torch.eye(n, dtype=torch.float64)
+        chol = torch.linalg.cholesky(sigma)
+        zz = torch.linalg.solve_triangular(chol, yt.reshape(-1, 1), upper=False)
+        lml = -0.5 * (zz**2).sum() - torch.log(torch.diagonal(chol)).sum() - 0.5 * n * np.log(2 * np.pi)
+        return -lml / n
+
+    return raw, loss_fn
+
+
+def test_lbfgs_trainer_follows_torch_lbfgs_on_an_autograd_restatement():
+    """the L-BFGS trainer must be torch.optim.LBFGS semantics (20 inner iterations per step, persistent
+    history, lr).  Same optimiser on (a) the engine's loss/gradient and (b) a torch-autograd restatement of the
+    reference model: identical loss trajectories (to the accuracy the two gradients agree)."""
+    n = 160
+    x, y = synthetic.make_cell_data(n, seed=21)
+    hyp0 = np.array([4e-6, 1e-12, 0.02, 20.0, 20.0, 20.0])
+    ranges = [cfg.NOISE_VARIANCE_RANGE, cfg.OUTPUTSCALE_WIENER_RANGE, cfg.OUTPUTSCALE_RBF_RANGE]
+    cell = BatteryCellGP_Full(
+        x, y, cellnr=1, noise_variance=hyp0[0], outputscale_wiener=hyp0[1], outputscale_rbf=hyp0[2], lengthscale_rbf=tuple(hyp0[3:])
+    )
+    max_iter, lr = 4, 0.5
+    got = training.train_exact_gp_lbfgs(cell.model, max_iter=max_iter, rel_ftol=0.0, loss_scale=n, lr=lr, messages=False)
+
+    raw, loss_fn = _torch_autograd_model(x, y, hyp0, ranges)
+    opt = torch.optim.LBFGS([raw], line_search_fn="strong_wolfe", lr=lr)
+
+    def closure():
+        opt.zero_grad()
+        loss = loss_fn()
+        loss.backward()
+        return loss
+
+    want = np.zeros(max_iter + 1) * np.nan
+    for i in range(max_iter):
+        with torch.no_grad():
+            last = float(loss_fn()) * n
+        want[i] = last
+        opt.step(closure)
+    want[-1] = last
+    assert got.shape == want.shape
+    assert np.allclose(got[:2], want[:2], rtol=1e-9)  # start point and the first full step (up to 20 inner iterations)
+    assert np.allclose(got, want, rtol=1e-5), (got, want)
+    assert got[max_iter - 1] < got[0] - 1.0  # it actually optimises
+    assert np.allclose(cell.model.raw_vector(), raw.detach().numpy(), rtol=1e-3, atol=1e-3)
+    assert np.all(np.isfinite(cell.model.raw_vector()))  # also for a parameter that saturated at its bound
+    del cell.model
+
+
+def test_adam_trainer_follows_torch_adam_on_an_autograd_restatement():
+    n = 120
+    x, y = synthetic.make_cell_data(n, seed=22)
+    hyp0 = np.array([4e-6, 1e-12, 0.02, 20.0, 20.0, 20.0])
+    ranges = [cfg.NOISE_VARIANCE_RANGE, cfg.OUTPUTSCALE_WIENER_RANGE, cfg.OUTPUTSCALE_RBF_RANGE]
+    cell = BatteryCellGP_Full(
+        x, y, cellnr=1, noise_variance=hyp0[0], outputscale_wiener=hyp0[1], outputscale_rbf=hyp0[2], lengthscale_rbf=tuple(hyp0[3:])
+    )
+    max_iter, lr = 12, 0.1
+    got = training.train_exact_gp_adam(cell.model, max_iter=max_iter, rel_ftol=0.0, loss_scale=n, lr=lr, messages=False)
+    raw, loss_fn = _torch_autograd_model(x, y, hyp0, ranges)
+    opt = torch.optim.Adam([raw], lr=lr)
+    want = np.zeros(max_iter + 1) * np.nan
+    for i in range(max_iter):
+        opt.zero_grad()
+        loss = loss_fn()
+        loss.backward()
+        want[i] = float(loss) * n
+        opt.step()
+    want[-1] = want[max_iter - 1]  # the reference re-evaluates the LAST forward output (training.py:57)
+    assert np.allclose(got, want, rtol=1e-7), (got, want)
+    del cell.model
+
+
+def test_training_data_replacement_reaches_the_gpu():
+    """same-shaped replacement of train_inputs / train_targets must not reuse the stale copy in HBM."""
+    x, y = synthetic.make_cell_data(300, seed=31)
+    x2, y2 = synthetic.make_cell_data(300, seed=32)
+    cell = BatteryCellGP_Full(x, y, cellnr=1)
+    lml1 = cell.model.fit()
+    cell.model.train_targets = torch.as_tensor(y2)
+    cell.model.train_inputs = (torch.as_tensor(x2),)
+    lml2 = cell.model.fit()
+    want = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x2, y2).fit().lml
+    assert abs(lml2 - want) < 1e-6 * abs(want) and abs(lml1 - lml2) > 1e-3
+    # a hyper-parameter change alone takes the resident path (no upload) and still sees the new data
+    cell.model.outputscale_rbf = 0.02
+    hyp = synthetic.HYP_BATTGP.copy()
+    hyp[2] = 0.02
+    want = OracleGP(K.KERNEL_BATTGP, hyp, x2, y2).fit().lml
+    assert abs(cell.model.fit() - want) < 1e-6 * abs(want)
+    del cell.model
+
+
+def test_n_devices_needs_a_process_group_of_that_size():
+    from battgp_amd.engine import EngineError
+
+    x, y = synthetic.make_cell_data(64, seed=1)
+    with pytest.raises(EngineError, match="torch.distributed.run"):
+        BatteryCellGP_Full(x, y, cellnr=1, n_devices=2)
+    with pytest.raises(ValueError):
+        BatteryCellGP_Full(x, y, cellnr=1, n_devices=0)
+
+
+def test_hyperparameter_csv_layout(tmp_path):
+    import pandas as pd
+
+    x, y = synthetic.make_cell_data(80, seed=2)
+    cell = BatteryCellGP_Full(x, y, cellnr=7)
+    cell.marginallikelihood = -123.5
+    cell.save_hyperparameters(str(tmp_path))
+    df = pd.read_csv(tmp_path / "7hyperparams.csv", index_col=0)
+    assert list(df.index) == [
+        "Noise Variance", "Wiener Outputscale", "RBF Outputscale", "RBF Lengthscale 1", "RBF Lengthscale 2", "RBF Lengthscale 3",
+        "Marginal Likelihood",
+    ]
+    assert list(df.columns) == ["params"]
+    assert float(df.loc["RBF Lengthscale 2", "params"]) == cfg.LENGTHSCALE_RBF[1]
+    assert float(df.loc["Marginal Likelihood", "params"]) == -123.5
+    del cell.model
+
+
+def test_wiener_rbf_kernel_wrapper_matches_oracle():
+    """battgp_amd.wiener_kernel.WienerRBFKernel = `kernel(x1, x2).to_dense()` of the reference's composition
+    (src/gp/wiener_kernel.py:10-32 inside src/batt_models/cell_gp.py:32-36)."""
+    from battgp_amd.wiener_kernel import WienerRBFKernel
+
+    x1, _ = synthetic.make_cell_data(90, seed=3)
+    x2, _ = synthetic.make_cell_data(41, seed=4)
+    k = WienerRBFKernel(synthetic.OUTPUTSCALE_WIENER, synthetic.OUTPUTSCALE_RBF, synthetic.LENGTHSCALE_RBF)
+    hyp = np.concatenate(([0.0], synthetic.HYP_BATTGP[1:]))
+    assert np.allclose(k(x1, x2), K.kernel_matrix(K.KERNEL_BATTGP, hyp, x1, x2), rtol=2e-13, atol=1e-300)
+    sym = k(x1)
+    assert np.allclose(sym, K.kernel_matrix(K.KERNEL_BATTGP, hyp, x1), rtol=2e-13, atol=1e-300)
+    assert np.allclose(np.diag(sym), K.kernel_diag(K.KERNEL_BATTGP, hyp, x1), rtol=1e-13)  # diag=True branch
+    k.close()

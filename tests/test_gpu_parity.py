@@ -527,3 +527,26 @@ def test_lookahead_depth_does_not_change_a_single_bit(scheme):
     for lml, m, v, a in out[1:]:
         assert lml == out[0][0]
         assert np.array_equal(m, out[0][1]) and np.array_equal(v, out[0][2]) and np.array_equal(a, out[0][3])
+
+
+def test_unsorted_time_column_takes_the_general_wiener_path():
+    """The training fill uses min(t_i, t_j) = t_j below the diagonal only when the time column is ascending (checked on
+    the device at upload); shuffled rows must give the same GP (LML, posterior) through the general formula."""
+    n = 1700
+    x, y = synthetic.make_cell_data(n, seed=77)
+    xq = synthetic.make_query(x, 40)
+    perm = np.random.default_rng(5).permutation(n)
+    ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
+    m_ref, v_ref = ref.predict(xq, clamp=False)
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    for xs, ys in ((x, y), (x[perm], y[perm])):
+        lml, mean, var = e.fit_predict(xs, ys, xq, min_var=-1.0)
+        assert abs(lml - ref.lml) <= REL * abs(ref.lml)
+        assert rel_err(mean, m_ref) <= REL
+        assert np.max(np.abs(var - v_ref)) <= 1e-9 * synthetic.OUTPUTSCALE_RBF
+    # ties in the time column are "sorted" too: both formulas agree on them
+    xt = x.copy()
+    xt[100:110, 0] = xt[100, 0]
+    ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, xt, y).fit()
+    assert abs(e.fit(xt, y) - ref.lml) <= REL * abs(ref.lml)
+    e.close()

@@ -32,7 +32,14 @@ def test_sharded_single_rank_matches_oracle_and_engine(n, nb):
     e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
     assert abs(e.fit(x, y) - lml) < 1e-9 * abs(lml)
     e.close()
-    gp.engine.close()
+    # a second fit on the same object (resident buffers, new hyper-parameters) and the timers
+    hyp2 = synthetic.HYP_BATTGP.copy()
+    hyp2[2] *= 2.0
+    gp.set_hyp(hyp2)
+    lml2 = gp.fit(x, y)
+    assert abs(lml2 - OracleGP(K.KERNEL_BATTGP, hyp2, x, y).fit().lml) < 1e-6 * abs(lml2)
+    assert set(gp.timers()) == {"fit_s", "predict_s"}
+    gp.close()
 
 
 def test_sharded_matern_and_jitter():
@@ -40,13 +47,24 @@ def test_sharded_matern_and_jitter():
     gp = make_sharded_gp(K.KERNEL_MATERN32, synthetic.HYP_MATERN32, nb=256)
     lml = gp.fit(x, y)
     assert abs(lml - OracleGP(K.KERNEL_MATERN32, synthetic.HYP_MATERN32, x, y).fit().lml) < 1e-6 * abs(lml)
-    gp.engine.close()
+    gp.close()
     # exactly singular matrix -> first jitter rung, same as the single-GPU engine
     xs, ys = np.zeros((130, 2)), np.ones(130)
     gp = make_sharded_gp(K.KERNEL_BATTGP, np.array([0.0, 1.0, 1.0, 1.0]), nb=64)
     gp.fit(xs, ys)
     assert gp.jitter == 1e-8
-    gp.engine.close()
+    gp.close()
+    # failure in a LATER panel: the device flag poisons the enqueued pipeline, the host sees it once at the end
+    xs[:64, 1] = 3.0 * np.arange(64)
+    gp = make_sharded_gp(K.KERNEL_BATTGP, np.array([0.0, 1.0, 1.0, 1.0]), nb=64)
+    gp.fit(xs, ys)
+    assert gp.jitter == 1e-8
+    from battgp_amd.engine import NotPSDError
+
+    gp.max_tries = 0  # the plain attempt only
+    with pytest.raises(NotPSDError, match="leading minor 65"):
+        gp.fit(xs, ys)
+    gp.close()
 
 
 def _two_rank_worker(rank, world, port, n, nb, q):
@@ -68,8 +86,9 @@ def _two_rank_worker(rank, world, port, n, nb, q):
     mean, var = gp.predict(xq)
     q.put((rank, lml, mean.tolist(), var.tolist()))
     parallel.barrier(gp.dist)
-    gp.engine.close()
-    gp.dist.destroy_process_group()
+    dist = gp.dist
+    gp.close()
+    dist.destroy_process_group()
 
 
 @pytest.mark.timeout(280)
@@ -172,17 +191,84 @@ def test_update_panels_dev_against_numpy():
     for lc, w, off in panels:
         rows_j = rows_p - off
         r0 = 100 + off  # where this panel's diagonal sits in the store (any row offset works)
-        desc.append([lc * ld + r0, rows_j, w, off])
+        desc.append([lc * ld + r0, rows_j, w, off, ld])
         upd = p[off:] @ p[off : off + w].T
         ti = np.arange(rows_j)[:, None] // 128
         tj = np.arange(w)[None, :] // 128
         blk = want[r0 : r0 + rows_j, lc : lc + w]
         blk[ti >= tj] -= upd[ti >= tj]
     d = np.ascontiguousarray(desc, dtype=np.int64)
-    rc = lib.bgp_update_panels_dev(e._h, C.c_void_p(ts.data_ptr()), ld, d.ctypes.data_as(C.POINTER(C.c_int64)), len(desc),
-                                   C.c_void_p(tp.data_ptr()), rows_p, k)
+    flag = torch.zeros(1, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    rc = lib.bgp_update_panels_dev(e._h, C.c_void_p(ts.data_ptr()), d.ctypes.data_as(C.POINTER(C.c_int64)), len(desc),
+                                   C.c_void_p(tp.data_ptr()), rows_p, k, C.c_void_p(flag.data_ptr()))
     assert rc == 0
     assert lib.bgp_sync(e._h) == 0
     got = ts.cpu().numpy().T
     assert np.allclose(got, want, rtol=1e-12, atol=1e-10)
+    # a set abort flag (int in the low word of the slot) turns the launches into no-ops
+    flag.view(torch.int32)[0] = 7
+    torch.cuda.synchronize()
+    rc = lib.bgp_update_panels_dev(e._h, C.c_void_p(ts.data_ptr()), d.ctypes.data_as(C.POINTER(C.c_int64)), len(desc),
+                                   C.c_void_p(tp.data_ptr()), rows_p, k, C.c_void_p(flag.data_ptr()))
+    assert rc == 0 and lib.bgp_sync(e._h) == 0
+    assert np.array_equal(ts.cpu().numpy().T, got)
     e.close()
+
+
+def _plugin_worker(rank, world, port, n, q):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from battgp_amd import synthetic
+    from battgp_amd.battcellgp_full import BatteryCellGP_Full
+    from battgp_amd.operating_point import Op
+
+    dist.init_process_group("gloo")
+    x, y = synthetic.make_cell_data(n, seed=12)
+    cell = BatteryCellGP_Full(x, y, cellnr=3, n_devices=world, device=0)  # the reference's multi-GPU switch
+    t = np.linspace(x[0, 0], x[-1, 0], 40)
+    df = cell.predict_r0_op(Op(*synthetic.REF_OP), t)
+    loss = cell.model.neg_mll() * n
+    q.put((rank, df["r0_acausal_c3"].tolist(), df["r0var_acausal_c3"].tolist(), loss))
+    dist.barrier()
+    del cell.model
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(280)
+def test_plugin_n_devices_routes_to_the_sharded_engine():
+    """BatteryCellGP_Full(..., n_devices=2) inside a 2-rank process group = ONE GP over two ranks (here sharing the
+    test box's single GPU over gloo): same posterior and loss as the oracle, identical on both ranks."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n, world = 1500, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_plugin_worker, args=(r, world, port, n, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    x, y = synthetic.make_cell_data(n, seed=12)
+    t = np.linspace(x[0, 0], x[-1, 0], 40)
+    xq = np.column_stack((t, np.full(40, synthetic.REF_OP[0]), np.full(40, synthetic.REF_OP[1]), np.full(40, synthetic.REF_OP[2])))
+    ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
+    m_ref, v_ref = ref.predict(xq)
+    for rank, mean, var, loss in res:
+        assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
+        assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+        assert abs(loss - ref.neg_mll_scaled) < 1e-6 * abs(ref.neg_mll_scaled)
+    assert res[0][1:] == res[1][1:]

@@ -15,12 +15,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class NumpyBackend:
-    """Same interface as battgp_amd.sharded.DeviceBackend, numpy arithmetic (tests only)."""
+    """Same interface as battgp_amd.sharded.DeviceBackend, numpy arithmetic (tests only).  Buffers are flat numpy
+    arrays; a panel is addressed as (buffer, element offset, leading dimension) like on the device."""
 
     def __init__(self, kernel_id, hyp):
+        import torch
+
         from oracle import kernels as K
 
         self.K, self.kid, self.hyp = K, kernel_id, np.asarray(hyp, dtype=np.float64)
+        self.torch = torch
+        self.flag = 0
 
     def zeros(self, n):
         return np.zeros(int(n))
@@ -37,17 +42,17 @@ class NumpyBackend:
     def sync(self):
         pass
 
-    def after_comm(self):
-        pass
+    def scalar(self, v):
+        return np.array([float(v)])
 
     @staticmethod
     def _cm(buf, off, rows, cols, ld):
         """column-major view [rows, cols] at element offset `off`"""
         return np.lib.stride_tricks.as_strided(buf[off:], (rows, cols), (8, 8 * ld))
 
-    def fill_panel(self, store, ld, lcol0, x, n, d, col0, ncols, rows, y, extra_diag):
-        aug = 64
-        nr = rows - aug
+    # ---- factorisation ----
+    def fill_panel(self, store, off, ld, x, n, d, col0, ncols, rows, y, extra_diag):
+        nr = rows - 64
         blk = np.zeros((nr, ncols))
         idx_r = np.arange(col0, col0 + nr)
         idx_c = np.arange(col0, col0 + ncols)
@@ -57,55 +62,76 @@ class NumpyBackend:
         for c in range(ncols):
             j = col0 + c
             blk[c, c] = blk[c, c] + self.hyp[0] + extra_diag if j < n else 1.0
-        self._cm(store, lcol0 * ld + col0, nr, ncols, ld)[:] = blk
-        a = np.zeros((aug, ncols))
+        self._cm(store, off, nr, ncols, ld)[:] = blk
+        a = np.zeros((64, ncols))
         a[0, vc] = y[idx_c[vc]]
-        self._cm(store, lcol0 * ld + (ld - aug), aug, ncols, ld)[:] = a
+        self._cm(store, off + nr, 64, ncols, ld)[:] = a
 
-    def factor_panel(self, store, ld, lcol0, col0, rows, nbk, inv):
-        p = self._cm(store, lcol0 * ld + col0, rows, nbk, ld)
-        try:
-            l11 = np.linalg.cholesky(np.tril(p[:nbk]) + np.tril(p[:nbk], -1).T)
-        except np.linalg.LinAlgError:
-            return 1
-        p[:nbk] = l11
-        p[nbk:] = np.linalg.solve(l11, p[nbk:].T).T
-        return 0
+    def flag_reset(self):
+        self.flag = 0
 
-    def factor_pack(self, store, ld, lcol0, col0, rows, nbk, inv, pbuf):
-        info = self.factor_panel(store, ld, lcol0, col0, rows, nbk, inv)
-        if info == 0:
-            self.pack_panel(store, ld, lcol0, col0, rows, nbk, pbuf)
-        return info
+    def factor_pack(self, store, off, ld, rows, nbk, inv, pbuf, col0):
+        if self.flag == 0:  # a poisoned pipeline does nothing
+            p = self._cm(store, off, rows, nbk, ld)
+            sym = np.tril(p[:nbk]) + np.tril(p[:nbk], -1).T
+            try:
+                l11 = np.linalg.cholesky(sym)
+                p[:nbk] = l11
+                p[nbk:] = np.linalg.solve(l11, p[nbk:].T).T
+                pbuf[: nbk * rows] = p.T.reshape(-1)
+            except np.linalg.LinAlgError:
+                minor = next(i + 1 for i in range(nbk) if np.linalg.eigvalsh(sym[: i + 1, : i + 1])[0] <= 0)
+                self.flag = col0 + minor
+        pbuf[nbk * rows] = float(self.flag)
 
-    def pack_panel(self, store, ld, lcol0, col0, rows, nbk, pbuf):
-        pbuf[: nbk * rows] = self._cm(store, lcol0 * ld + col0, rows, nbk, ld).T.reshape(-1)
+    def flag_merge(self, pbuf, idx):
+        if self.flag == 0 and pbuf[idx] != 0:
+            self.flag = int(pbuf[idx])
 
-    def update_panel(self, store, ld, lcol0, colj, rows_j, nbj, pbuf, ldp, off, nbk):
-        pm = self._cm(pbuf, off, rows_j, nbk, ldp)
-        self._cm(store, lcol0 * ld + colj, rows_j, nbj, ld)[:] -= pm @ pm[:nbj].T
+    def flag_read(self):
+        return self.flag
 
-    def update_panels(self, store, ld, items, pbuf, ldp, nbk):
-        for lc, cj, rows_j, nbj, off in items:
-            self.update_panel(store, ld, lc, cj, rows_j, nbj, pbuf, ldp, off, nbk)
+    def update_panels(self, store, items, pbuf, ldp, nbk, flag_idx):
+        if flag_idx is not None and pbuf[flag_idx] != 0:
+            return
+        for c_off, ldc, rows_j, nbj, p_off in items:
+            pm = self._cm(pbuf, p_off, rows_j, nbk, ldp)
+            self._cm(store, c_off, rows_j, nbj, ldc)[:] -= pm @ pm[:nbj].T
 
-    def diag_logsum(self, store, ld, lcol0, col0, nbk):
-        return float(np.sum(np.log(np.diag(self._cm(store, lcol0 * ld + col0, nbk, nbk, ld)))))
+    def diag_logsum(self, store, off, ld, nbk):
+        return float(np.sum(np.log(np.diag(self._cm(store, off, nbk, nbk, ld)))))
 
-    def aug_row(self, store, ld, lcol0, nbk):
-        return self._cm(store, lcol0 * ld + (ld - 64), 1, nbk, ld)[0].copy()
+    def aug_row(self, store, off, ld, rows, nbk):
+        return self._cm(store, off + rows - 64, 1, nbk, ld)[0].copy()
 
+    # ---- collectives: numpy buffers wrapped in place ----
+    def _t(self, a):
+        return self.torch.from_numpy(a)
+
+    def bcast_start(self, dist, t, src):
+        return dist.broadcast(self._t(t), src=src, async_op=True)
+
+    def bcast_wait(self, work):
+        work.wait()
+
+    def allreduce(self, dist, t, op=None):
+        dist.all_reduce(self._t(t)) if op is None else dist.all_reduce(self._t(t), op=op)
+
+    def reduce(self, dist, t, dst):
+        dist.reduce(self._t(t), dst=dst)
+
+    # ---- prediction ----
     def cross_fill(self, xq, m, mpad, x, n, d, npad, out, lde):
         self._cm(out, 0, m, n, lde)[:] = self.K.kernel_matrix(self.kid, self.hyp, xq, x)
 
-    def solve_panel(self, e, lde, ecol0, me, store, ld, lcol0, col0, nbk, inv):
-        l11 = np.tril(self._cm(store, lcol0 * ld + col0, nbk, nbk, ld))
-        ek = self._cm(e, ecol0 * lde, me, nbk, lde)
+    def solve_panel(self, e, eoff, lde, me, store, off, ld, nbk, inv):
+        l11 = np.tril(self._cm(store, off, nbk, nbk, ld))
+        ek = self._cm(e, eoff, me, nbk, lde)
         ek[:] = np.linalg.solve(l11, ek.T).T
 
-    def update_rows(self, w, lde, wcol0, me, ek, ldek, store, ld, lcol0, row0, nrows, nbk):
-        l21 = self._cm(store, lcol0 * ld + row0, nrows, nbk, ld)
-        self._cm(w, wcol0 * lde, me, nrows, lde)[:] -= self._cm(ek, 0, me, nbk, ldek) @ l21.T
+    def update_rows(self, w, woff, lde, me, ek, ldek, store, off, ld, nrows, nbk):
+        l21 = self._cm(store, off, nrows, nbk, ld)
+        self._cm(w, woff, me, nrows, lde)[:] -= self._cm(ek, 0, me, nbk, ldek) @ l21.T
 
     def sumsq(self, v, n):
         return float(np.dot(v[:n], v[:n]))
@@ -114,9 +140,18 @@ class NumpyBackend:
         var = self.K.kernel_diag(self.kid, self.hyp, xq) - ssq[:m]
         return np.maximum(var, min_var) if min_var >= 0 else var
 
-    def rowdot(self, e, lde, m, n, vec, out):
+    def rowdot(self, e, lde, m, n, vec, voff, out):
         em = self._cm(e, 0, m, n, lde)
-        out[:m] = em @ vec if vec is not None else np.einsum("ij,ij->i", em, em)
+        out[:m] = em @ vec[voff : voff + n] if vec is not None else np.einsum("ij,ij->i", em, em)
+
+    def add_into(self, acc, t):
+        acc += t
+
+    def copy_into(self, dst, src):
+        dst[:] = src
+
+    def set_segment(self, vec, c0, seg):
+        vec[c0 : c0 + seg.shape[0]] = seg
 
 
 def _free_port():
@@ -162,7 +197,7 @@ def _run(world, n, nb):
 
 
 @pytest.mark.timeout(200)
-@pytest.mark.parametrize("world,n,nb", [(2, 330, 64), (2, 500, 128), (3, 449, 64)])
+@pytest.mark.parametrize("world,n,nb", [(2, 330, 64), (2, 500, 128), (3, 449, 64), (4, 700, 64)])
 def test_sharded_gp_matches_oracle(world, n, nb):
     from battgp_amd import synthetic
     from oracle import kernels as K
@@ -188,7 +223,60 @@ def test_panel_layout():
     assert [lay.owner(j) for j in range(8)] == [0, 1, 2, 3, 0, 1, 2, 3]
     assert lay.local_panels(1) == [1, 5] and lay.local_index(5) == 1
     assert lay.rows_from(3) == 1088 - 384
+    # every panel keeps only the rows from its own diagonal down: offsets are cumulative trimmed panels
+    off, total = lay.offsets(1)
+    assert off == {1: 0, 5: lay.ld(1) * 128} and total == (lay.ld(1) + lay.ld(5)) * 128
+    assert lay.ld(1) == 1088 - 128 and lay.ld(5) == 1088 - 640
+    big = PanelLayout(4096 - 64, 512, 2)
+    assert big.rows_from(0) == 4096 and big.ld(0) == 4096 + 64  # bumped off the power-of-two stride
     lay = PanelLayout(200, 128, 2)
     assert lay.npad == 256 and lay.width(1) == 128 and lay.npanels == 2
     lay = PanelLayout(330, 128, 2)
     assert lay.npad == 384 and lay.npanels == 3 and lay.width(2) == 128
+
+
+def _jitter_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from battgp_amd import parallel
+    from battgp_amd.engine import NotPSDError
+    from battgp_amd.sharded import ShardedExactGP
+    from test_sharded_cpu import NumpyBackend
+
+    dist = parallel.init("gloo")
+    # exactly singular covariance, no noise: 64 well-separated points, then copies of the first one - the plain attempt
+    # fails at leading minor 65, i.e. in the SECOND panel (owned by rank 1); the flag reaches every rank behind the
+    # packed panel and all ranks retry with jitter 1e-8
+    xs, ys = np.zeros((130, 2)), np.ones(130)
+    xs[:64, 1] = 3.0 * np.arange(64)
+    gp = ShardedExactGP(NumpyBackend(0, np.array([0.0, 1.0, 1.0, 1.0])), dist, rank, world, nb=64)
+    gp.fit(xs, ys)
+    jit = gp.jitter
+    # a matrix no jitter can rescue: every rank raises
+    gp2 = ShardedExactGP(NumpyBackend(0, np.array([0.0, 1.0, 1.0, 1.0])), dist, rank, world, nb=64, max_tries=1, jitter0=-5.0)
+    try:
+        gp2.fit(xs, ys)
+        raised = False
+    except NotPSDError:
+        raised = True
+    q.put((rank, jit, raised))
+    parallel.barrier(dist)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(200)
+def test_sharded_jitter_ladder_is_agreed_by_all_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_jitter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=170) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [1e-8, 1e-8]
+    assert all(r[2] for r in res)

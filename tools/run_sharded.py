@@ -48,9 +48,10 @@ def main():
             "lml": lml, "jitter": gp.jitter, "mean_first": [float(v) for v in mean[:3]], "var_first": [float(v) for v in var[:3]],
         }), flush=True)
     parallel.barrier(gp.dist)
-    gp.engine.close()
-    if gp.dist is not None:
-        gp.dist.destroy_process_group()
+    dist = gp.dist
+    gp.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
