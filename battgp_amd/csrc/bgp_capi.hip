@@ -538,8 +538,8 @@ void free_problem(bgp_handle* h) {
   dev_free(h, &h->dy, h->N);
   dev_free(h, &h->dE, h->E_rows_cap * h->Npad);
   h->E_rows_cap = 0;
-  dev_free(h, &h->dB, h->lda * h->Npad);
-  dev_free(h, &h->dS, h->lda * h->Npad);
+  dev_free(h, &h->dB, h->B_ld * h->B_n);
+  h->B_ld = h->B_n = 0;
   dev_free(h, &h->dLinvAll, h->LinvAll_cap);
   h->LinvAll_cap = 0;
   h->LinvAll_nb = 0;
@@ -593,10 +593,12 @@ inline void apply_auto_nb(bgp_handle* h, int64_t n) {
 
 int alloc_problem(bgp_handle* h, int64_t N, int D, int64_t Mride) {
   const int64_t aug_need = BGP_AUG + round_up(Mride, 64);
-  if (h->N == N && h->D == D && h->dA && h->aug_cap >= aug_need) return 0;
-  free_problem(h);
   const int64_t Npad = round_up(N, BGP_IB);
+  // the automatic panel width is a function of the size alone: a revived pooled handle (reset to the default width)
+  // that finds its parked buffers must factor with the same blocking as a fresh one
   apply_auto_nb(h, Npad);
+  if (h->N == N && h->D == D && h->dA && h->aug_cap >= aug_need && (h->slabW >= h->Npad || (h->slabW % h->nb_outer) == 0)) return 0;
+  free_problem(h);
   // rows below the matrix: 64 for the augmented block (row Npad = y^T) + the query rows that ride
   // through the factorisation (bgp_fit_predict); avoid large power-of-two column strides (all
   // columns of a tile in one HBM channel)
@@ -1055,6 +1057,12 @@ int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, 
   if (nb_outer >= 0) {
     if (nb_outer < 64 || (nb_outer % 64) != 0 || nb_outer > 2048)
       return bgp_fail(h, -1, "nb_outer must be a multiple of 64 in [64, 2048]");
+    if (nb_outer != h->nb_outer) {
+      // the stored factor, its panel inverses and a slab layout were built for the old width: the solve / predict /
+      // gradient drivers must not walk them with the new one - a new fit is required first
+      h->fitted = false;
+      h->LinvAll_nb = 0;
+    }
     h->nb_outer = nb_outer;
     h->nb_auto = false;
   }
@@ -1652,32 +1660,44 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   if (!h->fitted || !grad_out) return bgp_fail(h, -1, "bgp_lml_grad: no successful fit / NULL output");
   if (ngrad != h->nhyp) return bgp_fail(h, -1, "bgp_lml_grad: expected %d entries, got %d", h->nhyp, ngrad);
   hipStream_t st = h->s_main;
-  const int64_t N = h->N, n = h->Npad, lda = h->lda, NB = h->nb_outer;
-  if (!h->dB && (rc = dev_alloc(h, &h->dB, lda * n))) return rc;
-  if (!h->dS && (rc = dev_alloc(h, &h->dS, lda * n))) return rc;
-  double *U = h->dB, *S = h->dS;
-  const SlabView L = h->view();  // U and S are plain [lda, n] squares of their own
+  const int64_t N = h->N, n = h->Npad, NB = h->nb_outer;
+  // ONE extra square: U = L^-T (upper) is built in it and then overwritten IN PLACE by the upper triangle of
+  // P = U U^T = Sigma^-1 (blocked LAUUM, every product in the NT form of the MFMA kernel)
+  int64_t ldb = n;
+  if (ldb >= 2048 && (ldb % 512) == 0) ldb += 64;
+  if (h->dB && h->B_ld != ldb) {
+    dev_free(h, &h->dB, h->B_ld * h->B_n);
+    h->B_ld = h->B_n = 0;
+  }
+  if (!h->dB) {
+    if ((rc = dev_alloc(h, &h->dB, ldb * n))) return rc;
+    h->B_ld = ldb;
+    h->B_n = n;
+  }
+  double* U = h->dB;
+  const SlabView L = h->view();
   const double* inv = h->dInv;
   PhaseTimer t(h, st, BGP_T_SOLVE);
   // (1) U = I L^-T (upper triangular): the identity pushed through the panel operations row-block-wise;
-  //     a row only becomes active at the panel that contains its diagonal element  -> N^3/3 flop
-  if ((rc = launch_set_identity(h, st, U, lda, n))) return rc;
+  //     a row only becomes active at the panel that contains its diagonal element  -> N^3/3 flop.
+  //     The strict lower triangle of the square stays exactly zero (step (2) relies on it).
+  if ((rc = launch_set_identity(h, st, U, ldb, n))) return rc;
   for (int64_t K0 = 0; K0 < n; K0 += NB) {
     const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
     const int64_t K1 = K0 + nbk;
     for (int64_t j = K0; j < K1; j += BGP_IB) {
       const int64_t act = j + BGP_IB;  // active rows [0, act)
-      double* Uj = U + j * lda;
-      if ((rc = launch_gemm_nt(h, st, 1, 64, Uj, lda, Uj, lda, inv + (j / BGP_IB) * (BGP_IB * BGP_IB), BGP_IB, act,
+      double* Uj = U + j * ldb;
+      if ((rc = launch_gemm_nt(h, st, 1, 64, Uj, ldb, Uj, ldb, inv + (j / BGP_IB) * (BGP_IB * BGP_IB), BGP_IB, act,
                                BGP_IB, BGP_IB, 0)))
         return rc;
       const int64_t ncols = K1 - (j + BGP_IB);
       if (ncols > 0 &&
-          (rc = launch_gemm_nt(h, st, 0, ncols >= 128 ? 128 : 64, U + (j + BGP_IB) * lda, lda, Uj, lda,
+          (rc = launch_gemm_nt(h, st, 0, ncols >= 128 ? 128 : 64, U + (j + BGP_IB) * ldb, ldb, Uj, ldb,
                                L.at(j + BGP_IB, j), L.ld(j), act, ncols, BGP_IB, 0)))
         return rc;
     }
-    if (n - K1 > 0 && (rc = launch_gemm_nt(h, st, 0, 128, U + K1 * lda, lda, U + K0 * lda, lda, L.at(K1, K0), L.ld(K0),
+    if (n - K1 > 0 && (rc = launch_gemm_nt(h, st, 0, 128, U + K1 * ldb, ldb, U + K0 * ldb, ldb, L.at(K1, K0), L.ld(K0),
                                            K1, n - K1, nbk, 0)))
       return rc;
   }
@@ -1686,18 +1706,33 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   if (!h->alpha_ready) {
     if ((rc = ensure_part(h, ((n + BGP_RD_COLS - 1) / BGP_RD_COLS + 1) * n))) return rc;
     int nch = 0;
-    if ((rc = launch_rowdot(h, st, U, lda, n, n, h->dz, h->dpart, &nch))) return rc;
+    if ((rc = launch_rowdot(h, st, U, ldb, n, n, h->dz, h->dpart, &nch))) return rc;
     FillParams p0;
     memset(&p0, 0, sizeof(p0));
     if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, n, nullptr, &p0, -1.0, h->dalpha))) return rc;
     h->alpha_ready = true;
   }
-  // (2) S = -Sigma^-1 = -U U^T (lower): per k-panel only rows [0, K1) of U are non-zero  -> N^3/3 flop
-  BGP_HIP(h, hipMemsetAsync(S, 0, (size_t)lda * (size_t)n * sizeof(double), st));
-  for (int64_t K0 = 0; K0 < n; K0 += NB) {
-    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
-    const int64_t K1 = K0 + nbk;
-    if ((rc = launch_gemm_nt(h, st, 0, 128, S, lda, U + K0 * lda, lda, U + K0 * lda, lda, K1, K1, nbk, 1))) return rc;
+  // (2) P = U U^T in place, upper triangle, panel by panel from the left (a panel only reads columns to its right,
+  //     which are still U):
+  //       P[0:c0, p]   = U[0:c0, p] U_pp^T                      (through a workspace: the product is not in place)
+  //       P_pp         = U_pp U_pp^T                            (ditto; the whole symmetric block is written)
+  //       P[0:c1, p]  += U[0:c1, c1:n] U[c0:c1, c1:n]^T         (one deep NT GEMM, MODE 3)       -> N^3/3 flop
+  if ((rc = ensure_part(h, n * NB + NB * NB))) return rc;
+  double* Wtall = h->dpart;           // [c0, nb], ld = c0
+  double* Wdiag = h->dpart + n * NB;  // [nb, nb]
+  for (int64_t c0 = 0; c0 < n; c0 += NB) {
+    const int64_t nb = (n - c0 < NB) ? (n - c0) : NB;
+    const int64_t c1 = c0 + nb;
+    double* Upp = U + c0 + c0 * ldb;
+    double* Ucol = U + c0 * ldb;  // rows 0.. of the panel's columns
+    if (c0 > 0) {
+      if ((rc = launch_gemm_nt(h, st, 1, 64, Wtall, c0, Ucol, ldb, Upp, ldb, c0, nb, nb, 0))) return rc;
+      if ((rc = launch_copy_panel(h, st, Wtall, c0, Ucol, ldb, c0, (int)nb))) return rc;
+    }
+    if ((rc = launch_gemm_nt(h, st, 1, 64, Wdiag, nb, Upp, ldb, Upp, ldb, nb, nb, nb, 0))) return rc;
+    if ((rc = launch_copy_panel(h, st, Wdiag, nb, Upp, ldb, nb, (int)nb))) return rc;
+    if (c1 < n && (rc = launch_gemm_nt(h, st, 3, 128, Ucol, ldb, U + c1 * ldb, ldb, U + c0 + c1 * ldb, ldb, c1, nb, n - c1, 0)))
+      return rc;
   }
   // (3) fused reduction of 1/2 tr(W dSigma/dtheta)
   FillParams p;
@@ -1705,7 +1740,7 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   const int64_t nblk = grad_blocks(N);
   const int nacc = grad_nacc();
   if ((rc = ensure_part(h, nblk * nacc))) return rc;
-  if ((rc = launch_grad_reduce(h, st, p, h->dX, N, S, lda, h->dalpha, h->dpart, h->dscal))) return rc;
+  if ((rc = launch_grad_reduce(h, st, p, h->dX, N, U, ldb, h->dalpha, h->dpart, h->dscal))) return rc;
   BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, nacc * sizeof(double), hipMemcpyDeviceToHost, st));
   if ((rc = t.stop())) return rc;
   const double* a = h->hscal;

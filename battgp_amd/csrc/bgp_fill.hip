@@ -69,6 +69,29 @@ __device__ __forceinline__ double exp_nonpos(double x, const double* __restrict_
   return exp_nonpos_t<false>(x, tbl);
 }
 
+// The interior tiles' exponential: finite x <= 0, a 256-entry table 2^(i/256) (times the output scale) in LDS, so
+// |r| <= ln2/512 and a degree-4 polynomial suffices (truncation r^5/120 <= 3.8e-17): one FMA less per entry than
+// the 64-entry / degree-5 version above.
+__device__ __forceinline__ double exp_interior(double x, const double* __restrict__ tbl256) {
+  const double INV = 4.0 * 92.33248261689366;       // 256 / ln2
+  const double L_HI = 0.25 * 0.01083042469326756;  // ln2/256 (the low bits stay zero under the power-of-two scaling)
+  const double L_LO = 0.25 * 2.9815858269852933e-12;
+  const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+  x = __builtin_fmax(x, -4194304.0);        // keeps k = x * 256/ln2 inside 32 bits; the result is 0 there anyway
+  const double z = __builtin_fma(x, INV, MAGIC);
+  const int k = __double2loint(z);
+  const double kd = z - MAGIC;
+  double r = __builtin_fma(kd, -L_HI, x);
+  r = __builtin_fma(kd, -L_LO, r);
+  const double t = tbl256[k & 255];
+  double p = 4.1666666666666664e-02;               // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);  // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(t * p, k >> 8);
+}
+
 // sqrt(q), q >= 0, to ~1.5 ulp: v_rsq_f64 seed (2^-26) times q, then ONE residual correction with the seed's own
 // half-reciprocal, r += (q - r^2) y / 2: the error is ~1.5 (2^-26)^2.  5 VALU ops (+ the quarter-rate rsq); the
 // coupled Newton step that brings it to 0.5 ulp costs 3 more and 2.4 % of the Matern fill rate; the library
@@ -190,7 +213,7 @@ __device__ __forceinline__ double kfun_interior(const double (&a)[DD], const dou
         const double df = a[d] - b[d];
         q = __builtin_fma(df, df, q);
       }
-    const double e = exp_nonpos_t<true>(-q, tbl);  // s_r e^-q
+    const double e = exp_interior(-q, tbl);  // s_r e^-q
     if (SORTED) return __builtin_fma(w[0], a[0], w[1]) + e;
     const double m = __builtin_fmin(a[0], b[0]);
     const double mx = __builtin_fmax(a[0], b[0]);
@@ -208,7 +231,7 @@ __device__ __forceinline__ double kfun_interior(const double (&a)[DD], const dou
     const double y = __builtin_amdgcn_rsq(q);
     double r = q * y;
     r = __builtin_fma(__builtin_fma(-r, r, q), 0.5 * y, r);
-    const double se = exp_nonpos_t<true>(-r, tbl);  // s e^-r
+    const double se = exp_interior(-r, tbl);  // s e^-r
     return __builtin_fma(r, se, se);
   } else {
     double q = 0.0;
@@ -218,7 +241,7 @@ __device__ __forceinline__ double kfun_interior(const double (&a)[DD], const dou
         const double df = a[d] - b[d];
         q = __builtin_fma(df, df, q);
       }
-    return exp_nonpos_t<true>(-q, tbl);
+    return exp_interior(-q, tbl);
   }
 }
 
@@ -241,12 +264,14 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
   const int D = DT ? DT : p.D;
   __shared__ double sB[FT_COLS][DD];
   __shared__ double sW[FT_COLS][2];  // K0: A_j = s_w t_j^2 / 2, B_j = -s_w t_j^3 / 6
-  __shared__ double sT[64];          // 2^(i/64) ...
-  __shared__ double sTs[64];         // ... and the same times the output scale (s_r for K0, s otherwise)
-  const double oscale = (KID == BGP_KERNEL_BATTGP) ? p.s1 : p.s0;
-  if (threadIdx.x < 64) {
-    sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
-    sTs[threadIdx.x] = EXP2_TBL[threadIdx.x] * oscale;
+  __shared__ double sT[64];          // 2^(i/64): the general path's table ...
+  __shared__ double sTs[256];        // ... and 2^(i/256) times the output scale (s_r for K0, s otherwise): interior tiles
+  {
+    const double oscale = (KID == BGP_KERNEL_BATTGP) ? p.s1 : p.s0;
+    // 2^(1/256), 2^(2/256), 2^(3/256) correctly rounded; 2^(i/256) = 2^((i >> 2)/64) 2^((i & 3)/256) to ~1 ulp
+    const double fine[4] = {1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175};
+    if (threadIdx.x < 64) sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
+    sTs[threadIdx.x] = (EXP2_TBL[threadIdx.x >> 2] * fine[threadIdx.x & 3]) * oscale;
   }
 
   int ti, tj;
@@ -456,8 +481,8 @@ __global__ __launch_bounds__(64) void llt_sample_kernel(FillParams p, const doub
 
 
 // ---- LML gradient reduction ------------------------------------------------------------------
-//   d lml / d theta = 1/2 sum_jk W_jk dSigma_jk/dtheta,   W = alpha alpha^T + S,  S = -Sigma^-1 (lower)
-// One pass over the lower triangle (same 512 x 32 tiling as the fill), kernel derivatives
+//   d lml / d theta = 1/2 sum_jk W_jk dSigma_jk/dtheta,   W = alpha alpha^T - P,  P = Sigma^-1 (UPPER triangle stored)
+// One pass over the upper triangle (512 x 32 tiles, rows contiguous like the fill), kernel derivatives
 // re-evaluated on the fly, NACC partial sums per workgroup (deterministic two-stage reduction):
 //   acc[0] = sum W_jj (j < N)                              -> d/d noise
 //   acc[1] = sum' W_jk * wiener(t_j, t_k)      (K0 only)   -> d/d s_wiener
@@ -466,10 +491,29 @@ __global__ __launch_bounds__(64) void llt_sample_kernel(FillParams p, const doub
 // where sum' counts each off-diagonal pair twice (symmetry) and the diagonal once.
 constexpr int GR_NACC = 3 + BGP_MAX_DIM;
 
+// upper trapezoid: column tile tj (32 columns) needs the row tiles ti <= tj / FT_RATIO (512 rows each).  Column tiles
+// are grouped by g = tj / FT_RATIO: FT_RATIO column tiles x (g + 1) row tiles;  prefix(g) = FT_RATIO g (g + 1) / 2.
+__device__ __forceinline__ bool upper_decode(int64_t t, int ntj, int& ti, int& tj) {
+  auto prefix = [&](int64_t q) { return (int64_t)FT_RATIO * q * (q + 1) / 2; };
+  int64_t g = (int64_t)((__builtin_sqrt(1.0 + 8.0 * (double)t / FT_RATIO) - 1.0) * 0.5);
+  if (g < 0) g = 0;
+  while (g > 0 && prefix(g) > t) --g;
+  while (prefix(g + 1) <= t) ++g;
+  const int64_t r = t - prefix(g);
+  tj = (int)(g * FT_RATIO + r / (g + 1));
+  ti = (int)(r % (g + 1));
+  return tj < ntj;
+}
+
+__host__ int64_t upper_blocks(int ntj) {
+  const int64_t G = (ntj + FT_RATIO - 1) / FT_RATIO;
+  return (int64_t)FT_RATIO * G * (G + 1) / 2;
+}
+
 template <int KID>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const double* __restrict__ x, int64_t n,
-                                                          const double* __restrict__ S, int64_t lds_,
-                                                          const double* __restrict__ alpha, int nti, int ntj,
+                                                          const double* __restrict__ P, int64_t ldp,
+                                                          const double* __restrict__ alpha, int ntj,
                                                           double* __restrict__ part) {
   constexpr int DD = BGP_MAX_DIM;
   const int D = p.D;
@@ -483,7 +527,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const do
   for (int q = 0; q < GR_NACC; ++q) acc[q] = 0.0;
 
   int ti, tj;
-  const bool valid_tile = lower_decode((int64_t)blockIdx.x, nti, ntj, ti, tj);
+  const bool valid_tile = upper_decode((int64_t)blockIdx.x, ntj, ti, tj);
   if (valid_tile) {
     const int64_t i0 = (int64_t)ti * FT_ROWS, j0 = (int64_t)tj * FT_COLS;
     for (int idx = threadIdx.x; idx < FT_COLS * DD; idx += 256) {
@@ -512,9 +556,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const do
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int64_t ii = i + r;
-        if (ii >= n || ii < j) continue;  // padding / strict upper triangle
+        if (ii > j) continue;  // strict lower triangle (and, since j < n, everything past the matrix)
         const double wgt = (ii == j) ? 1.0 : 2.0;
-        const double W = wgt * (al[r] * sAl[c] + S[ii + j * lds_]);
+        const double W = wgt * (al[r] * sAl[c] - P[ii + j * ldp]);
         if (ii == j) acc[0] += W;
         double q = 0.0, u2[DD];
 #pragma unroll
@@ -623,14 +667,14 @@ int launch_llt_sample(bgp_handle* h, hipStream_t st, const FillParams& p, const 
 
 int grad_nacc() { return GR_NACC; }
 
-int64_t grad_blocks(int64_t n) { return lower_blocks((int)((n + FT_ROWS - 1) / FT_ROWS)); }
+int64_t grad_blocks(int64_t n) { return upper_blocks((int)((n + FT_COLS - 1) / FT_COLS)); }
 
 int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n,
-                       const double* S, int64_t lds_, const double* alpha, double* part, double* out) {
-  const int nti = (int)((n + FT_ROWS - 1) / FT_ROWS), ntj = (int)((n + FT_COLS - 1) / FT_COLS);
-  const int64_t nb = lower_blocks(nti);
-  BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((grad_reduce_kernel<KID_>), dim3((unsigned)nb), dim3(256), 0, st, p, x, n, S,
-                                           lds_, alpha, nti, ntj, part));
+                       const double* P, int64_t ldp, const double* alpha, double* part, double* out) {
+  const int ntj = (int)((n + FT_COLS - 1) / FT_COLS);
+  const int64_t nb = upper_blocks(ntj);
+  BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((grad_reduce_kernel<KID_>), dim3((unsigned)nb), dim3(256), 0, st, p, x, n, P,
+                                           ldp, alpha, ntj, part));
   BGP_HIP(h, hipGetLastError());
   hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(1024), 0, st, part, nb, out);
   BGP_HIP(h, hipGetLastError());

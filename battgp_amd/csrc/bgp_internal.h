@@ -95,8 +95,9 @@ struct bgp_handle {
   double* dInv = nullptr;    // [Npad/64][64*64] inverses of the diagonal tiles of L
   double* dz = nullptr;      // [Npad] z = L^-1 y (zero in the padding)
   double* dalpha = nullptr;  // [Npad]
-  double* dB = nullptr;      // gradient workspace: U = L^-T (upper), [lda, Npad]; allocated on first bgp_lml_grad
-  double* dS = nullptr;      // gradient workspace: S = -Sigma^-1 (lower), [lda, Npad]
+  double* dB = nullptr;      // gradient workspace [B_ld, B_n]: U = L^-T (upper), overwritten in place by the upper triangle of
+                             // Sigma^-1 = U U^T; allocated on first bgp_lml_grad
+  int64_t B_ld = 0, B_n = 0;
   double* dLinvAll = nullptr;  // inv(L_pp) of every outer panel [npanels][nbL * nbL]: later query blocks (predict after fit)
   int64_t LinvAll_cap = 0;
   int64_t LinvAll_nb = 0;      // panel width they were built for; 0 = not valid for the current factor

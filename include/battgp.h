@@ -93,7 +93,8 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
 
 /* Tuning / numerical options.  Any argument < 0 (or NaN) keeps the current value.
  *   nb_outer         outer panel width of the blocked Cholesky (multiple of 64 in [64, 2048]; default: 512 below
- *                    N = 32 768, 1024 from there on)
+ *                    N = 32 768, 1024 from there on).  Changing it invalidates the stored factor: fit again before
+ *                    the next predict / gradient call
  *   max_tries        rungs of the jitter ladder after the plain attempt (default 3)
  *   jitter0          first rung (default 1e-8: linear_operator psd_safe_cholesky, fp64)
  *   lookahead        bits 0-2: depth d of the look-ahead (0 = off, default 1, <= 4): the panel stream factors
@@ -157,9 +158,9 @@ int bgp_fit_predict_dev(bgp_handle* h, const double* X_dev, const double* y_dev,
 
 /* Gradient of the LML of the last fit w.r.t. the hyper-parameter vector (same layout as hyp):
  *   d lml / d theta_i = 1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta_i).
- * Sigma^-1 is formed explicitly on the GPU (U = L^-T, then U U^T: 2/3 N^3 flop on the MFMA kernel, two
- * extra N^2 buffers kept on the handle), followed by one fused pass that re-evaluates the kernel
- * derivatives.  Replaces the autograd backward of src/gp/training.py:41 (loss.backward()) up to the
+ * Sigma^-1 is formed explicitly on the GPU (U = L^-T, then U U^T in place over U: 2/3 N^3 flop on the MFMA kernel,
+ * ONE extra N^2 buffer kept on the handle), followed by one fused pass over its upper triangle that re-evaluates the
+ * kernel derivatives.  Replaces the autograd backward of src/gp/training.py:41 (loss.backward()) up to the
  * factor -1/N and the raw-parameter chain rule, which stay on the host. */
 int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad);
 
