@@ -3,8 +3,13 @@
 feather + json.  Same public behaviour as the reference's ``BattGP_Full`` / ``BattGP`` / ``BattGPResult``
 (``src/batt_models/battgp_full.py:15-125``, ``src/batt_models/battgp.py:16-262``) - so the
 ``gp_runner.py`` ``full_gp`` branch (``:68-96``) and ``calc_fault_probabilities`` consume it unchanged -
-with two MI355X-native additions: ``devices=`` spreads the (independent) GPs over several GPUs, one
-GP per GPU at a time, and models are freed right after use because one N x N fp64 factor fills a card.
+with MI355X-native additions: the 1 + n_cells GPs of a system are independent, so at the reference's sizes
+(N = 1000 ... 16 000 per cell, where one GP is a latency-bound chain of small kernels using a fraction of the 256 CUs)
+they are driven CONCURRENTLY on the one GPU - one engine handle and stream set each, one host thread each, the
+C-ABI calls release the GIL (``in_flight=``; automatic: as many as fit into half of the free HBM); ``devices=``
+spreads them over several GPUs; and models are freed right after use because at the large sizes one N x N fp64
+factor fills a card.  Every GP runs the same kernels on its own buffers whatever the concurrency: the numbers
+do not depend on it.
 """
 
 from __future__ import annotations
@@ -73,6 +78,7 @@ class BattGP_Full:
         device=None,
         devices: Optional[list] = None,
         save_path: Optional[str] = None,
+        in_flight: Optional[int] = None,
         **kwargs,
     ) -> None:
         if max_training_data is None:
@@ -93,6 +99,8 @@ class BattGP_Full:
             os.makedirs(self.save_path, exist_ok=True)
         # one device for everything (the reference), or a list to deal the 1 + n_cells GPs over
         self.devices = list(devices) if devices else [device]
+        # GPs in flight per device: None = automatic (see _in_flight), 1 = the reference's strictly sequential loop
+        self.in_flight = in_flight
         cells = [-1] + list(batt_data.cell_nrs)
         models = [
             build_cellmodel_full(
@@ -163,26 +171,63 @@ class BattGP_Full:
         # would cost 34 ms per cell here and is not needed
         del model.model
 
+    def _in_flight(self, models, n_query: int, listed: int = 1) -> int:
+        """How many GPs of one device run at the same time.  ``in_flight=`` decides when given; a device listed ``c``
+        times in ``devices=`` asks for ``c``; otherwise automatic: up to ``AUTO_IN_FLIGHT_MAX_N`` points per GP the
+        factorisation is a latency-bound chain that leaves most of the chip idle, so as many GPs as fit into half of
+        the device's free memory (each holds its factor ``8 (N + 64 + M) N`` bytes plus panel workspaces) run
+        together; larger GPs fill the chip on their own and run one after another."""
+        if self.in_flight is not None:
+            return max(1, min(int(self.in_flight), len(models)))
+        if listed > 1:
+            return min(listed, len(models))
+        n = max(int(m.model.train_targets.shape[0]) for m in models)
+        if n > self.AUTO_IN_FLIGHT_MAX_N:
+            return 1
+        per_gp = 8.0 * (n + 64 + n_query) * n * 1.1 + 64e6
+        try:
+            import torch
+
+            free, _total = torch.cuda.mem_get_info(models[0].device_)
+        except Exception:  # no GPU visible: the engine will say so on the first call
+            return 1
+        return max(1, min(len(models), int(0.5 * free / per_gp)))
+
+    AUTO_IN_FLIGHT_MAX_N = 20000
+
     def predict_cell_r0_op(self, destroy_after_run: bool = True, add_time_steps: bool = False, save: bool = True) -> BattGPResult:
         self.t = self._time_grid(add_time_steps)
         models = [self.packmodel, *self.cellmodels]
         frames: list[Optional[pd.DataFrame]] = [None] * len(models)
         keep = len(models) - 1  # the last cell model stays alive for the plots (plotting.py:233,259)
 
-        def run(idxs):
-            for i in idxs:
-                frames[i] = models[i].predict_r0_op(op=self.ref_op, t=self.t)
-                if destroy_after_run and i != keep:
-                    self._free(models[i])
+        def run_one(i):
+            frames[i] = models[i].predict_r0_op(op=self.ref_op, t=self.t)
+            if destroy_after_run and i != keep:
+                self._free(models[i])
 
-        if len(self.devices) == 1:
-            run(range(len(models)))
+        # the constructor bound model i to devices[i % n]; the models of one (distinct) device share a queue served by
+        # that device's worker threads
+        by_device: dict = {}
+        for i in range(len(models)):
+            by_device.setdefault(str(self.devices[i % len(self.devices)]), []).append(i)
+        lanes = list(by_device.values())
+        listed = [sum(str(d) == key for d in self.devices) for key in by_device]
+        workers = [self._in_flight([models[i] for i in lane], len(self.t), c) for lane, c in zip(lanes, listed)]
+        if sum(workers) <= 1:
+            for i in range(len(models)):
+                run_one(i)
         else:
             from concurrent.futures import ThreadPoolExecutor
 
-            groups = [[i for i in range(len(models)) if i % len(self.devices) == d] for d in range(len(self.devices))]
-            with ThreadPoolExecutor(len(groups)) as pool:
-                list(pool.map(run, groups))
+            lane_pools = [ThreadPoolExecutor(w) for w in workers]
+            try:
+                futures = [lp.submit(run_one, i) for lp, lane in zip(lane_pools, lanes) for i in lane]
+                for f in futures:
+                    f.result()  # re-raises a worker's exception (NotPSDError, EngineError) in the caller
+            finally:
+                for lp in lane_pools:
+                    lp.shutdown(wait=True)
         # every frame carries the same time grid self.t, so the reference's chain of DataFrame.merge() calls on
         # "t" (battgp_full.py:100-121; ~1 ms each) is a column-wise concatenation - as long as the grid has no
         # repeated time stamps: on repeated keys merge() yields their cross product (add_time_steps=True repeats

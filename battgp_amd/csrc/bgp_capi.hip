@@ -848,15 +848,16 @@ int check_handle(bgp_handle* h) {
 // (src/batt_models/battgp_full.py:41-60,102-120): bgp_create + first fit + bgp_destroy are paid per cell -
 // measured 8.5 ms + 8.5 ms for streams / events / pinned buffers and, at N = 40 000, +147 ms for the
 // hipMalloc and first touch of the 13 GB factor, against 339 ms of work.  bgp_destroy therefore parks the
-// handle WITH its buffers (at most BGP_POOL = 2 per device; BGP_POOL=0 disables), bgp_create revives one
-// for the same device, and a same-sized problem finds its buffers in place.  Parked memory is given back
-// when an allocation fails or the automatic layout needs it, and by bgp_trim().
+// handle WITH its buffers (at most BGP_POOL = 16 per device - one system's 1 + 8 GPs run concurrently on one
+// GPU, battgp_full.py - holding at most BGP_POOL_BYTES = 40 GiB of buffers between them; BGP_POOL=0 disables),
+// bgp_create revives one for the same device, and a same-sized problem finds its buffers in place.  Parked
+// memory is given back when an allocation fails or the automatic layout needs it, and by bgp_trim().
 namespace {
 struct HandlePool {
   std::mutex mu;
   std::vector<bgp_handle*> idle;
-  int max_per_device = 2;
-  int64_t max_bytes = (int64_t)40 << 30;  // a parked handle keeps its buffers only up to this size (BGP_POOL_BYTES)
+  int max_per_device = 16;
+  int64_t max_bytes = (int64_t)40 << 30;  // buffers kept by ALL parked handles of a device together (BGP_POOL_BYTES)
   bool init = false;
 };
 HandlePool& pool() {
@@ -1019,11 +1020,16 @@ void bgp_destroy(bgp_handle* h) {
     std::lock_guard<std::mutex> lk(p.mu);
     pool_init_locked(p);
     int same = 0;
-    for (bgp_handle* q : p.idle) same += q->device == h->device;
+    int64_t parked = 0;
+    for (bgp_handle* q : p.idle)
+      if (q->device == h->device) {
+        ++same;
+        parked += q->bytes;
+      }
     if (h->s_main && same < p.max_per_device) {
       // big problems give their HBM back at once (N = 131 072 would park 138 GB that torch or the next,
       // differently sized model may need); the shell - streams, events, pinned buffers - is still worth keeping
-      if (h->bytes > p.max_bytes) {
+      if (parked + h->bytes > p.max_bytes) {
         free_problem(h);
         free_panel_ws(h);
       }

@@ -74,8 +74,9 @@ int bgp_version(void);
  * `del cellmodel.model; gc.collect(); torch.cuda.empty_cache()` does in the reference
  * (src/batt_models/battgp_full.py:102-120) - with the allocator behaviour of torch: the reference
  * builds one model per cell and deletes it after the prediction (battgp_full.py:41-60), so a destroyed
- * handle is PARKED with its streams, events and - up to BGP_POOL_BYTES = 40 GiB - buffers (at most
- * BGP_POOL = 2 per device, environment variables; BGP_POOL=0 = free at once) and the next bgp_create on
+ * handle is PARKED with its streams, events and buffers (at most BGP_POOL = 16 per device holding at most
+ * BGP_POOL_BYTES = 40 GiB of buffers between them - a handle that would exceed that parks without its
+ * buffers; environment variables; BGP_POOL=0 = free at once) and the next bgp_create on
  * that device revives it as a logically new handle; a problem of the same size then finds its buffers in place (measured per cell: -17 ms, and -147 ms of hipMalloc + first touch
  * at N = 40 000).  Parked memory is released when an allocation fails, when the automatic layout needs
  * it, and by bgp_trim(device) (device < 0: all devices) - the counterpart of torch.cuda.empty_cache(). */

@@ -202,3 +202,68 @@ def test_cells_for_rank_deals_nine_gps_over_eight_gpus():
     assert cells_for_rank(cells, 0, 8) == [-1, 8]
     assert cells_for_rank(cells, 7, 8) == [7]
     assert sorted(sum((cells_for_rank(cells, r, 8) for r in range(8)), [])) == sorted(cells)
+
+
+def test_system_driver_concurrency_is_a_scheduling_choice_only(monkeypatch):
+    """BattGP_Full.predict_cell_r0_op: sequential, automatic and explicit ``in_flight`` / ``devices=[0]*k`` must hand
+    back the same frame (each GP is computed by its own model whatever runs next to it), run at most the requested
+    number of models at a time, free every model but the last, and re-raise a worker's exception in the caller."""
+    import threading
+    import time
+
+    import pandas as pd
+
+    from battgp_amd import battgp_full
+    from battgp_amd.synthetic import SyntheticBattData
+
+    state = {"now": 0, "peak": 0, "freed": [], "lock": threading.Lock(), "fail": None}
+
+    class FakeModel:
+        def __init__(self, cellnr, n):
+            import torch
+
+            self.cellnr = cellnr
+            self.device_ = "cuda:0"
+            self.model = type("M", (), {})()
+            self.model.train_inputs = (torch.arange(4.0 * n, dtype=torch.float64).reshape(n, 4),)
+            self.model.train_targets = torch.zeros(n, dtype=torch.float64)
+
+        def predict_r0_op(self, op, t):
+            with state["lock"]:
+                state["now"] += 1
+                state["peak"] = max(state["peak"], state["now"])
+            time.sleep(0.02)
+            with state["lock"]:
+                state["now"] -= 1
+            if state["fail"] == self.cellnr:
+                raise RuntimeError(f"cell {self.cellnr} failed")
+            tag = "pack" if self.cellnr == -1 else f"c{self.cellnr}"
+            return pd.DataFrame({"t": t, f"r0_acausal_{tag}": t * (self.cellnr + 2), f"r0var_acausal_{tag}": t * 0 + self.cellnr})
+
+        def __delattr__(self, name):
+            if name == "model":
+                state["freed"].append(self.cellnr)
+            super().__delattr__(name)
+
+    monkeypatch.setattr(battgp_full, "build_cellmodel_full", lambda c, bd, max_training_data, max_age=None, device=None, **kw: FakeModel(c, 50))
+    bd = SyntheticBattData("conc", n_cells=8, seed=1)
+
+    def run(**kw):
+        state.update(now=0, peak=0, freed=[])
+        sysm = battgp_full.BattGP_Full(bd, max_training_data=50, **kw)
+        return sysm.predict_cell_r0_op(save=False).df
+
+    ref = run(device=0, in_flight=1)
+    assert state["peak"] == 1 and sorted(state["freed"]) == [-1, 1, 2, 3, 4, 5, 6, 7]  # the last cell model stays alive
+    assert ref.shape == (300, 1 + 2 * 9)
+    for kw, peak in (({"device": 0, "in_flight": 4}, 4), ({"devices": [0, 0, 0]}, 3), ({"devices": [0, 1], "in_flight": 2}, 4)):
+        df = run(**kw)
+        assert df.equals(ref), kw
+        assert 1 < state["peak"] <= peak, (kw, state["peak"])
+        assert sorted(state["freed"]) == [-1, 1, 2, 3, 4, 5, 6, 7]
+    # automatic: no GPU in this process -> mem_get_info fails -> sequential, never a crash
+    df = run(device=0)
+    assert df.equals(ref)
+    state["fail"] = 3
+    with pytest.raises(RuntimeError, match="cell 3 failed"):
+        run(device=0, in_flight=9)

@@ -240,6 +240,23 @@ def test_system_driver_end_to_end(tmp_path):
     assert sysm.get_cell_model(-1) is sysm.packmodel and sysm.get_cell_model(3).cellnr == 3
 
 
+def test_system_driver_concurrent_gps_bit_identical():
+    """The nine GPs of a system run concurrently on the one GPU (one handle + stream set + host thread each) by default
+    at the reference's sizes; the frame must be BIT-identical to the strictly sequential loop of the reference
+    (src/batt_models/battgp_full.py:100-121)."""
+    from battgp_amd.battgp_full import BattGP_Full
+    from battgp_amd.synthetic import SyntheticBattData
+
+    bd = SyntheticBattData("sysc", n_cells=8, seed=3)
+    seq = BattGP_Full(bd, max_training_data=1200, device=0, in_flight=1).predict_cell_r0_op(save=False).df
+    auto = BattGP_Full(bd, max_training_data=1200, device=0)
+    assert auto._in_flight([auto.packmodel, *auto.cellmodels], 300) == 9
+    conc = auto.predict_cell_r0_op(save=False).df
+    assert conc.shape == (300, 19) and conc.equals(seq)
+    three = BattGP_Full(bd, max_training_data=1200, device=0, in_flight=3).predict_cell_r0_op(save=False).df
+    assert three.equals(seq)
+
+
 def test_system_driver_add_time_steps_large_m():
     """add_time_steps=True (battgp_full.py:86-96): M = N + age query points ride through the factorisation."""
     from battgp_amd.battgp_full import BattGP_Full
