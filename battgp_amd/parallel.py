@@ -29,11 +29,13 @@ def cells_for_rank(cell_ids: Sequence[int], rank: int, world: int) -> list[int]:
     return [c for i, c in enumerate(cell_ids) if i % world == rank]
 
 
-def init(backend: str | None = None, device=None):
+def init(backend: str | None = None, device=None, force: bool = False):
     """Initialise the default process group when launched by torch.distributed.run; returns the
-    ``torch.distributed`` module or None for a single process."""
+    ``torch.distributed`` module or None for a single process.  ``force`` (or ``BGP_FORCE_GROUP=1``) builds the
+    group even for one process, so that every collective of the sharded path goes through the backend
+    (a 1-GPU box can put RCCL under the real call sequence that way)."""
     rank, world, _ = env_rank_world()
-    if world <= 1:
+    if world <= 1 and not (force or os.environ.get("BGP_FORCE_GROUP") == "1"):
         return None
     import torch.distributed as dist
 
@@ -45,6 +47,10 @@ def init(backend: str | None = None, device=None):
         kwargs = {}
         if backend == "nccl" and device is not None:
             kwargs["device_id"] = device
+        if world <= 1:  # forced single-process group: the launcher's rendezvous variables may be missing
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            kwargs.update(rank=0, world_size=1)
         dist.init_process_group(backend, **kwargs)
     return dist
 

@@ -430,7 +430,12 @@ def main() -> None:
     ap.add_argument("--sharded-n", type=int, default=98304, help="size of the ONE sharded GP appended to a multi-GPU cells run (0 = skip)")
     ap.add_argument("--sharded-nb", type=int, default=1024)
     ap.add_argument("--sharded-steps", type=int, default=1)
+    ap.add_argument("--force-group", action="store_true",
+                    help="build the process group even for ONE process, so that --mode sharded on a 1-GPU box sends every "
+                         "broadcast / all-reduce of the schedule through RCCL (single-rank proxy with the collectives in)")
     args = ap.parse_args()
+    if args.force_group:
+        os.environ["BGP_FORCE_GROUP"] = "1"
 
     import torch
 

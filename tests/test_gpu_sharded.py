@@ -121,6 +121,59 @@ def test_sharded_two_ranks_device_backend_over_gloo():
     assert res[0][1:] == res[1][1:]
 
 
+def _rccl_world1_worker(port, n, nb, q):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BGP_FORCE_GROUP="1")
+    import torch.distributed as dist
+
+    from battgp_amd import synthetic
+    from battgp_amd.sharded import make_sharded_gp
+
+    x, y = synthetic.make_cell_data(n, seed=11)
+    xq = synthetic.make_query(x, 33)
+    gp = make_sharded_gp(0, synthetic.HYP_BATTGP, nb=nb, backend_name="nccl")
+    assert gp.dist is not None and dist.get_backend() == "nccl"
+    lml = gp.fit(x, y)
+    mean, var = gp.predict(xq)
+    q.put((lml, mean.tolist(), var.tolist()))
+    gp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(280)
+def test_sharded_one_rank_group_over_rccl():
+    """A one-process "nccl" group: every broadcast / all-reduce / reduce of the sharded schedule goes through
+    ProcessGroupNCCL (= RCCL) on the engine's stream (ExternalStream hand-off, async work objects waited on the
+    device) - the calls a multi-GPU node issues, with one rank.  Result must equal the oracle."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n, nb = 1900, 256
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, n, nb, q))
+    p.start()
+    lml, mean, var = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    x, y = synthetic.make_cell_data(n, seed=11)
+    xq = synthetic.make_query(x, 33)
+    ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
+    m_ref, v_ref = ref.predict(xq)
+    assert abs(lml - ref.lml) < 1e-6 * abs(ref.lml)
+    assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
+    assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+
+
 def _colmajor(a, ld=None):
     m, n = a.shape
     ld = m if ld is None else ld

@@ -2,6 +2,8 @@
 Warm handle, median of `reps` fused fit+predict calls with the inputs resident in HBM.
 
     python tools/sweep_n.py [reps] [N ...]        -> one JSON line per (kernel, N)
+Environment (experiments): BGP_NB = outer panel width, BGP_SCHEME = panel scheme 0 / 1, BGP_LA = look-ahead word,
+BGP_ONLY = battgp | scaled_rbf.
 """
 import json
 import os
@@ -22,6 +24,8 @@ sizes = [int(a) for a in sys.argv[2:]] or [2048, 4096, 8192, 16384, 32768, 40000
 m = 300
 for kname, kid in (("battgp", KERNEL_BATTGP), ("scaled_rbf", KERNEL_SCALED_RBF)):
     for n in sizes:
+        if os.environ.get("BGP_ONLY", kname) != kname:
+            continue
         if kname == "scaled_rbf" and n not in (2048, 40000):  # BASELINE configs 1 and 2 name the plain RBF too
             continue
         x, y = synthetic.make_cell_data(n)
@@ -36,6 +40,10 @@ for kname, kid in (("battgp", KERNEL_BATTGP), ("scaled_rbf", KERNEL_SCALED_RBF))
         tv = torch.empty(m, dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
         eng = ExactGPEngine(kid, hyp, device=0)
+        if "BGP_NB" in os.environ or "BGP_LA" in os.environ:
+            eng.set_options(nb_outer=int(os.environ.get("BGP_NB", -1)), lookahead=int(os.environ.get("BGP_LA", -1)))
+        if "BGP_SCHEME" in os.environ:
+            eng.set_panel_scheme(int(os.environ["BGP_SCHEME"]))
         ts = []
         for r in range(reps + 1):
             t0 = time.perf_counter()
@@ -46,7 +54,7 @@ for kname, kid in (("battgp", KERNEL_BATTGP), ("scaled_rbf", KERNEL_SCALED_RBF))
         res = eng.residuals(128)
         flop = n**3 / 3.0 + float(n) * n * m + 2.0 * n * n
         print(json.dumps({
-            "kernel": kname, "n": n, "m": m, "fit_predict_ms": t * 1e3, "gflops": flop / t / 1e9,
+            "kernel": kname, "n": n, "m": m, "nb": os.environ.get("BGP_NB"), "scheme": os.environ.get("BGP_SCHEME"), "la": os.environ.get("BGP_LA"), "fit_predict_ms": t * 1e3, "gflops": flop / t / 1e9,
             "potrf_ms": ph["potrf_ms"], "fill_ms": ph["fill_ms"], "fill_gbs": ph["fill_bytes"] / (ph["fill_ms"] * 1e-3) / 1e9,
             "lml": eng.lml, "jitter": eng.jitter, "rel_solve": res[0], "max_llt": res[1],
         }), flush=True)
