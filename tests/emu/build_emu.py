@@ -1,0 +1,54 @@
+"""TEST INFRASTRUCTURE ONLY: builds tests/emu/_build/libbattgp_emu.so - the kernel and host SOURCES of
+battgp_amd/csrc compiled for this container's CPU against tests/emu/hip/hip_runtime.h (cooperative-fiber
+execution of the workgroups, see hipemu.cpp).  Used by tests/test_emu_kernels.py to check the kernels' indexing and
+algebra against the oracle while no GPU is at hand, and as the sanitizer target (``sanitize=True``).
+The product binding (battgp_amd/_lib.py) never looks here."""
+
+from __future__ import annotations
+
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "battgp_amd", "csrc")
+OUT_DIR = os.path.join(HERE, "_build")
+SOURCES = [os.path.join(CSRC, f) for f in ("bgp_fill.hip", "bgp_linalg.hip", "bgp_capi.hip")] + [os.path.join(HERE, "hipemu.cpp")]
+
+
+def _compiler() -> str:
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", "clang++"):
+        if os.path.exists(c) or c == "clang++":
+            return c
+    return "clang++"
+
+
+def build(sanitize: bool = False, force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    lib = os.path.join(OUT_DIR, "libbattgp_emu_san.so" if sanitize else "libbattgp_emu.so")
+    deps = SOURCES + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "bgp_internal.h"), os.path.join(ROOT, "include", "battgp.h")]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(d) for d in deps):
+        return lib
+    objs = []
+    flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-march=native", "-ffp-contract=fast", "-pthread", f"-I{HERE}", "-Wall",
+             "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable", "-Wno-unused-value"]
+    if sanitize:
+        flags += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"]
+    for src in SOURCES:
+        obj = os.path.join(OUT_DIR, os.path.basename(src) + (".san.o" if sanitize else ".o"))
+        cmd = [_compiler(), "-x", "c++", *flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [_compiler(), "-shared", "-pthread", *(["-fsanitize=undefined"] if sanitize else []), *objs, "-o", lib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return lib
+
+
+if __name__ == "__main__":
+    import sys
+
+    print(build(sanitize="--sanitize" in sys.argv, force=True, verbose=True))

@@ -1,0 +1,238 @@
+// tests/emu/hip/hip_runtime.h - TEST INFRASTRUCTURE ONLY.
+//
+// A host stand-in for <hip/hip_runtime.h> that lets the UNMODIFIED kernel and host sources of battgp_amd/csrc
+// be compiled for the build container's CPU ("the CPU build": logic tests of the kernels' indexing and
+// algebra while no GPU is at hand, and a target for sanitizers, which the GPU pool does not offer).  Threads
+// of a workgroup run as cooperative fibers; __syncthreads and the cross-lane operations (readlane, shuffles,
+// v_mfma_f64_16x16x4) are rendezvous points with the documented gfx950 lane layouts.  Streams are executed
+// in order and synchronously.  It says nothing about speed, memory-model races or occupancy.
+//
+// The product (battgp_amd/_lib.py) never loads the library built from this header: it is linked only into
+// tests/emu/_build/libbattgp_emu.so, which tests/test_emu_kernels.py injects into the binding by hand.
+#pragma once
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <cmath>
+#include <functional>
+
+#define HIPEMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct double2 {
+  double x, y;
+} __attribute__((aligned(16)));
+static inline double2 make_double2(double x, double y) {
+  double2 r;
+  r.x = x;
+  r.y = y;
+  return r;
+}
+
+// ---- error / stream / event API (synchronous, in order) ---------------------------------------------------
+enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+struct ihipStream_t {
+  int id;
+};
+typedef ihipStream_t* hipStream_t;
+struct ihipEvent_t {
+  double t_ms;
+};
+typedef ihipEvent_t* hipEvent_t;
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+#define hipHostMallocDefault 0
+
+namespace hipemu {
+double now_ms();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+struct Ctx {
+  dim3 tid, bid, bdim, gdim;
+};
+extern thread_local Ctx* g_ctx;  // the running fiber's coordinates
+// rendezvous primitives (all live lanes of the calling lane's wavefront / all live threads of its workgroup)
+uint64_t wave_xchg(uint64_t mine, int srclane, int fallback_self);
+int wave_first_lane();
+void wave_mfma_f64_16x16x4(double a, double b, double* d4, int neg_a);
+void block_barrier();
+int block_or(int pred);
+}  // namespace hipemu
+
+#define threadIdx (::hipemu::g_ctx->tid)
+#define blockIdx (::hipemu::g_ctx->bid)
+#define blockDim (::hipemu::g_ctx->bdim)
+#define gridDim (::hipemu::g_ctx->gdim)
+
+static inline const char* hipGetErrorString(hipError_t e) {
+  switch (e) {
+    case hipSuccess: return "hipSuccess";
+    case hipErrorInvalidValue: return "hipErrorInvalidValue";
+    case hipErrorOutOfMemory: return "hipErrorOutOfMemory";
+    default: return "hipError";
+  }
+}
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) {
+  *n = 1;
+  return hipSuccess;
+}
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
+  *free_b = (size_t)48 << 30;
+  *total_b = (size_t)64 << 30;
+  return hipSuccess;
+}
+static inline hipError_t hipMalloc(void** p, size_t bytes) {
+  void* q = nullptr;
+  // a bounded "device": sizes the GPU tests use to provoke an allocation failure (or that would swamp the build
+  // container) fail the same way here
+  const char* lim = getenv("HIPEMU_MEM_GB");
+  if (bytes > ((size_t)(lim ? atoi(lim) : 6) << 30)) return hipErrorOutOfMemory;
+  if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
+  memset(q, 0xA5, bytes < ((size_t)1 << 28) ? bytes : ((size_t)1 << 28));  // fresh device memory is NOT zero
+  *p = q;
+  return hipSuccess;
+}
+static inline hipError_t hipFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
+static inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+static inline hipError_t hipHostFree(void* p) { return hipFree(p); }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+  memmove(d, s, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
+  memmove(d, s, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind,
+                                          hipStream_t = nullptr) {
+  for (size_t r = 0; r < height; ++r) memmove(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+  return hipSuccess;
+}
+static inline hipError_t hipMemset(void* d, int v, size_t n) {
+  memset(d, v, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) {
+  memset(d, v, n);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  *s = new ihipStream_t{0};
+  return hipSuccess;
+}
+static inline hipError_t hipStreamDestroy(hipStream_t s) {
+  delete s;
+  return hipSuccess;
+}
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = new ihipEvent_t{0.0};
+  return hipSuccess;
+}
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) {
+  delete e;
+  return hipSuccess;
+}
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+  e->t_ms = ::hipemu::now_ms();
+  return hipSuccess;
+}
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = (float)(b->t_ms - a->t_ms);
+  return hipSuccess;
+}
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+  ::hipemu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
+
+// ---- device intrinsics --------------------------------------------------------------------------------------
+#define __syncthreads() ::hipemu::block_barrier()
+#define __syncthreads_or(p) ::hipemu::block_or(p)
+#define __threadfence_block() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+// v_rsq_f64 is a ~2^-26 seed on the GPU; every caller refines it, so the exact value is a valid stand-in
+#define __builtin_amdgcn_rsq(x) (1.0 / __builtin_sqrt((double)(x)))
+#define __builtin_amdgcn_readlane(v, l) ((int)::hipemu::wave_xchg((uint64_t)(uint32_t)(v), (l), 0))
+#define __builtin_amdgcn_readfirstlane(v) ((int)::hipemu::wave_xchg((uint64_t)(uint32_t)(v), ::hipemu::wave_first_lane(), 0))
+
+static inline int __double2loint(double v) {
+  uint64_t b;
+  memcpy(&b, &v, 8);
+  return (int)(uint32_t)b;
+}
+static inline int __double2hiint(double v) {
+  uint64_t b;
+  memcpy(&b, &v, 8);
+  return (int)(uint32_t)(b >> 32);
+}
+static inline double __hiloint2double(int hi, int lo) {
+  const uint64_t b = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+  double v;
+  memcpy(&v, &b, 8);
+  return v;
+}
+static inline double __shfl_down(double v, unsigned off) {
+  uint64_t b;
+  memcpy(&b, &v, 8);
+  const int lane = (int)((threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) & 63);
+  const int src = lane + (int)off;
+  b = ::hipemu::wave_xchg(b, src < 64 ? src : lane, 1);
+  memcpy(&v, &b, 8);
+  return v;
+}
+// D[m][n] += sum_k A[m][k] B[k][n];  lane l holds a = A[l & 15][l >> 4], b = B[l >> 4][l & 15] and, in register r,
+// D[(l >> 4) + 4 r][l & 15]  (the gfx950 f64 16x16x4 layout the kernels are written against); `neg` negates A
+template <class V4>
+static inline V4 hipemu_mfma_f64(double a, double b, V4 c, int neg) {
+  double d[4] = {c[0], c[1], c[2], c[3]};
+  ::hipemu::wave_mfma_f64_16x16x4(a, b, d, neg & 1);
+  V4 r;
+  r[0] = d[0];
+  r[1] = d[1];
+  r[2] = d[2];
+  r[3] = d[3];
+  return r;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, cbsz, abid, blgp) hipemu_mfma_f64((a), (b), (c), (blgp))
+
+static inline int atomicCAS(int* p, int expected, int desired) {
+  __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return expected;
+}
+static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static inline void unsafeAtomicAdd(double* p, double v) {
+  uint64_t old_b, new_b;
+  memcpy(&old_b, p, 8);
+  for (;;) {
+    double o;
+    memcpy(&o, &old_b, 8);
+    const double n = o + v;
+    memcpy(&new_b, &n, 8);
+    if (__atomic_compare_exchange_n(reinterpret_cast<uint64_t*>(p), &old_b, new_b, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return;
+  }
+}
+static inline uint64_t wall_clock64() {
+  return (uint64_t)(::hipemu::now_ms() * 1e5);  // 100 MHz like the GPU's constant-rate counter
+}
+static inline uint64_t clock64() { return __builtin_ia32_rdtsc(); }

@@ -1,0 +1,329 @@
+// tests/emu/hipemu.cpp - TEST INFRASTRUCTURE ONLY: the cooperative-fiber runtime behind tests/emu/hip/hip_runtime.h.
+//
+// A launch runs its workgroups on a few OS threads; the threads of ONE workgroup are fibers on one OS thread
+// (hand-rolled x86-64 context switch), scheduled round-robin.  A fiber runs until it reaches a rendezvous
+// (workgroup barrier or cross-lane operation); an operation completes when every LIVE thread of the group has
+// arrived (threads that returned from the kernel no longer count - like terminated wavefronts on the GPU).
+// If no fiber can run, the kernel has divergent lanes in a cross-lane operation or an unmatched barrier: abort
+// with a message instead of hanging.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <sys/mman.h>
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch, .-hipemu_switch
+)");
+
+namespace hipemu {
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+namespace {
+constexpr size_t STACK = 96 * 1024;
+constexpr int MAXT = 1024;
+
+enum State { READY = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
+
+struct Fiber {
+  void* sp;
+  Ctx ctx;
+  int lin, lane, wave;
+  State state;
+  uint64_t wait_gen;
+};
+
+struct Wave {
+  int live = 0, arrived = 0;
+  uint64_t gen = 0;
+  uint64_t slot[2][64];      // exchange buffers, double-buffered by generation parity
+  double ma[2][64], mb[2][64];  // MFMA operand buffers
+};
+
+struct Block {
+  Fiber fibers[MAXT];
+  Wave waves[MAXT / 64];
+  int nthreads = 0, live = 0, arrived = 0;
+  uint64_t gen = 0;
+  int orv[2] = {0, 0};
+  void* sched_sp = nullptr;
+  Fiber* cur = nullptr;
+  const std::function<void()>* body = nullptr;
+  char* stacks = nullptr;
+};
+
+thread_local Block* t_blk = nullptr;
+
+void yield_to_scheduler() {
+  Block* b = t_blk;
+  Fiber* f = b->cur;
+  hipemu_switch(&f->sp, b->sched_sp);
+}
+
+void release_wave_if_complete(Wave& w) {
+  if (w.live > 0 && w.arrived == w.live) {
+    w.arrived = 0;
+    ++w.gen;
+  }
+}
+void release_block_if_complete(Block* b) {
+  if (b->live > 0 && b->arrived == b->live) {
+    b->arrived = 0;
+    ++b->gen;
+    b->orv[b->gen & 1] = 0;  // the buffer of the NEXT barrier generation
+  }
+}
+
+void fiber_main() {
+  Block* b = t_blk;
+  Fiber* f = b->cur;
+  (*b->body)();
+  // thread leaves the kernel: it no longer takes part in any rendezvous
+  f->state = DONE;
+  Wave& w = b->waves[f->wave];
+  --w.live;
+  --b->live;
+  release_wave_if_complete(w);
+  release_block_if_complete(b);
+  yield_to_scheduler();
+  fprintf(stderr, "hipemu: finished fiber resumed\n");
+  abort();
+}
+
+// rendezvous of the live lanes of the caller's wave; returns the generation the caller arrived in
+uint64_t wave_arrive() {
+  Block* b = t_blk;
+  Fiber* f = b->cur;
+  Wave& w = b->waves[f->wave];
+  const uint64_t g = w.gen;
+  ++w.arrived;
+  if (w.arrived == w.live) {
+    w.arrived = 0;
+    ++w.gen;
+  } else {
+    f->state = WAIT_WAVE;
+    f->wait_gen = g;
+    yield_to_scheduler();
+  }
+  return g;
+}
+
+void run_block(Block* b, dim3 grid, dim3 block, dim3 bid, const std::function<void()>& body) {
+  const int nt = (int)(block.x * block.y * block.z);
+  b->nthreads = b->live = nt;
+  b->arrived = 0;
+  b->gen = 0;
+  b->orv[0] = b->orv[1] = 0;
+  b->body = &body;
+  const int nw = (nt + 63) / 64;
+  for (int w = 0; w < nw; ++w) {
+    b->waves[w].live = (w == nw - 1) ? nt - 64 * w : 64;
+    b->waves[w].arrived = 0;
+    b->waves[w].gen = 0;
+  }
+  for (int t = 0; t < nt; ++t) {
+    Fiber& f = b->fibers[t];
+    f.lin = t;
+    f.lane = t & 63;
+    f.wave = t >> 6;
+    f.state = READY;
+    f.wait_gen = 0;
+    f.ctx.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    f.ctx.bid = bid;
+    f.ctx.bdim = block;
+    f.ctx.gdim = grid;
+    char* top = b->stacks + (size_t)(t + 1) * STACK;  // 16-byte aligned
+    void** sp = reinterpret_cast<void**>(top);
+    *--sp = nullptr;                                  // fake return address of fiber_main's "caller"
+    *--sp = reinterpret_cast<void*>(&fiber_main);     // popped by `ret`
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;      // rbp rbx r12 r13 r14 r15
+    f.sp = sp;
+  }
+  t_blk = b;
+  while (b->live > 0) {
+    bool progressed = false;
+    for (int t = 0; t < nt; ++t) {
+      Fiber& f = b->fibers[t];
+      if (f.state == DONE) continue;
+      if (f.state == WAIT_WAVE && b->waves[f.wave].gen == f.wait_gen) continue;
+      if (f.state == WAIT_BLOCK && b->gen == f.wait_gen) continue;
+      f.state = READY;
+      b->cur = &f;
+      g_ctx = &f.ctx;
+      hipemu_switch(&b->sched_sp, f.sp);
+      progressed = true;
+    }
+    if (!progressed) {
+      int ww = 0, wb = 0;
+      for (int t = 0; t < nt; ++t) {
+        ww += b->fibers[t].state == WAIT_WAVE;
+        wb += b->fibers[t].state == WAIT_BLOCK;
+      }
+      fprintf(stderr,
+              "hipemu: deadlock in block (%u,%u,%u): %d threads live, %d waiting in a cross-lane operation, %d at a "
+              "workgroup barrier - divergent lanes inside a wave-level operation or an unmatched __syncthreads\n",
+              bid.x, bid.y, bid.z, b->live, ww, wb);
+      abort();
+    }
+  }
+  t_blk = nullptr;
+  g_ctx = nullptr;
+}
+
+Block* worker_block() {
+  static thread_local Block* b = nullptr;
+  if (!b) {
+    b = new Block();
+    void* m = mmap(nullptr, STACK * MAXT, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) {
+      perror("hipemu: mmap of fiber stacks");
+      abort();
+    }
+    b->stacks = static_cast<char*>(m);
+  }
+  return b;
+}
+
+int worker_count() {
+  static int n = [] {
+    const char* e = getenv("HIPEMU_THREADS");
+    int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+  }();
+  return n;
+}
+}  // namespace
+
+thread_local Ctx* g_ctx = nullptr;
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  const uint64_t nblocks = (uint64_t)grid.x * grid.y * grid.z;
+  const int nt = (int)(block.x * block.y * block.z);
+  if (nblocks == 0 || nt == 0) return;
+  if (nt > MAXT) {
+    fprintf(stderr, "hipemu: %d threads per workgroup\n", nt);
+    abort();
+  }
+  if (g_ctx != nullptr) {
+    fprintf(stderr, "hipemu: nested launch\n");
+    abort();
+  }
+  auto work = [&](std::atomic<uint64_t>* next) {
+    Block* b = worker_block();
+    for (;;) {
+      const uint64_t i = next->fetch_add(1);
+      if (i >= nblocks) break;
+      const dim3 bid((unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((uint64_t)grid.x * grid.y)));
+      run_block(b, grid, block, bid, body);
+    }
+  };
+  std::atomic<uint64_t> next{0};
+  const int nw = (int)std::min<uint64_t>(nblocks, (uint64_t)worker_count());
+  if (nw <= 1) {
+    work(&next);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int w = 0; w < nw; ++w) pool.emplace_back(work, &next);
+  for (auto& t : pool) t.join();
+}
+
+uint64_t wave_xchg(uint64_t mine, int srclane, int fallback_self) {
+  Block* b = t_blk;
+  Fiber* f = b->cur;
+  Wave& w = b->waves[f->wave];
+  const int buf = (int)(w.gen & 1);
+  w.slot[buf][f->lane] = mine;
+  wave_arrive();
+  const int base = f->wave * 64;
+  const bool src_ok = srclane >= 0 && srclane < 64 && base + srclane < b->nthreads;
+  if (!src_ok) {
+    if (fallback_self) return mine;
+    fprintf(stderr, "hipemu: cross-lane read from lane %d outside the wave\n", srclane);
+    abort();
+  }
+  return w.slot[buf][srclane];
+}
+
+int wave_first_lane() {
+  Block* b = t_blk;
+  Fiber* f = b->cur;
+  for (int l = 0; l < 64; ++l) {
+    const int t = f->wave * 64 + l;
+    if (t < b->nthreads && b->fibers[t].state != DONE) return l;
+  }
+  return f->lane;
+}
+
+void wave_mfma_f64_16x16x4(double a, double bv, double* d4, int neg_a) {
+  Block* b = t_blk;
+  Fiber* f = b->cur;
+  Wave& w = b->waves[f->wave];
+  if (w.live != 64) {
+    fprintf(stderr, "hipemu: MFMA with %d live lanes\n", w.live);
+    abort();
+  }
+  const int buf = (int)(w.gen & 1);
+  w.ma[buf][f->lane] = neg_a ? -a : a;
+  w.mb[buf][f->lane] = bv;
+  wave_arrive();
+  const int n = f->lane & 15, mq = f->lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int m = mq + 4 * r;
+    double acc = d4[r];
+    for (int k = 0; k < 4; ++k) acc = __builtin_fma(w.ma[buf][m + 16 * k], w.mb[buf][n + 16 * k], acc);
+    d4[r] = acc;
+  }
+}
+
+void block_barrier() {
+  Block* b = t_blk;
+  Fiber* f = b->cur;
+  const uint64_t g = b->gen;
+  ++b->arrived;
+  if (b->arrived == b->live) {
+    b->arrived = 0;
+    ++b->gen;
+    b->orv[b->gen & 1] = 0;
+  } else {
+    f->state = WAIT_BLOCK;
+    f->wait_gen = g;
+    yield_to_scheduler();
+  }
+}
+
+int block_or(int pred) {
+  Block* b = t_blk;
+  const int buf = (int)(b->gen & 1);
+  if (pred) b->orv[buf] = 1;
+  block_barrier();
+  return b->orv[buf];
+}
+
+}  // namespace hipemu

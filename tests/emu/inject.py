@@ -1,0 +1,111 @@
+"""TEST INFRASTRUCTURE ONLY: puts the CPU build of the kernel sources (build_emu.py) behind battgp_amd._lib for the
+duration of a test.  Nothing in battgp_amd/ knows about this module; the product has no way to reach it."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+_cache: dict = {}
+
+
+def load_emu(sanitize: bool = False) -> C.CDLL:
+    import build_emu
+
+    from battgp_amd import _lib
+
+    key = "san" if sanitize else "plain"
+    if key not in _cache:
+        lib = C.CDLL(build_emu.build(sanitize=sanitize))
+        for name, (res, args) in _lib.SIGNATURES.items():
+            fn = getattr(lib, name)  # the CPU build must export the whole C-ABI too
+            fn.restype = res
+            fn.argtypes = args
+        _cache[key] = lib
+    return _cache[key]
+
+
+class installed:
+    """``with installed(): ...`` - ExactGPEngine & co. talk to the CPU build inside the block."""
+
+    def __init__(self, sanitize: bool = False):
+        self.sanitize = sanitize
+
+    def __enter__(self):
+        from battgp_amd import _lib
+
+        self._saved = _lib._lib
+        _lib._lib = load_emu(self.sanitize)
+        return _lib._lib
+
+    def __exit__(self, *exc):
+        from battgp_amd import _lib
+
+        _lib._lib = self._saved
+        return False
+
+
+def fake_cuda_tensors():
+    """Development aid for ``pytest --emu``: the CPU build's "device memory" is host memory, so a test's
+    ``torch.zeros(..., device="cuda")`` / ``.cuda()`` / ``.to(cuda_device)`` may simply stay on the host and
+    ``data_ptr()`` is a valid "device pointer".  Patches the handful of torch entry points the tests use."""
+    import contextlib
+
+    import torch
+
+    def is_cuda(dev):
+        if dev is None:
+            return False
+        if isinstance(dev, int):
+            return True
+        try:
+            return torch.device(dev).type == "cuda"
+        except Exception:
+            return False
+
+    def strip(fn):
+        def wrapped(*a, **k):
+            if is_cuda(k.get("device")):
+                k = dict(k, device="cpu")
+            return fn(*a, **k)
+
+        return wrapped
+
+    for name in ("zeros", "empty", "full", "ones", "tensor", "as_tensor", "arange", "randn", "rand", "empty_like", "zeros_like", "linspace", "eye"):
+        setattr(torch, name, strip(getattr(torch, name)))
+    real_to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple("cpu" if (not isinstance(x, (torch.dtype, torch.Tensor, bool)) and is_cuda(x) and not isinstance(x, int)) else x for x in a)
+        if is_cuda(k.get("device")):
+            k = dict(k, device="cpu")
+        return real_to(self, *a, **k)
+
+    torch.Tensor.to = to
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: 1
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.empty_cache = lambda: None
+    torch.cuda.mem_get_info = lambda *a, **k: (48 << 30, 64 << 30)
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+
+    class _Stream:
+        def __init__(self, *a, **k):
+            pass
+
+        def synchronize(self):
+            pass
+
+        def wait_stream(self, other):
+            pass
+
+    torch.cuda.ExternalStream = _Stream
+    torch.cuda.current_stream = lambda *a, **k: _Stream()

@@ -1,0 +1,164 @@
+"""CPU build of the kernel sources (tests/emu): the UNMODIFIED battgp_amd/csrc/*.hip compiled for the host against a
+stand-in <hip/hip_runtime.h> whose workgroups run as cooperative fibers (barriers, readlane / shuffles and the f64
+16x16x4 MFMA with the gfx950 lane layout).  These tests run a selection of the ``-m gpu`` parity tests - the very same
+test functions, imported from their modules - through that build, at sizes a CPU finishes in seconds: the kernels'
+indexing and algebra (fill, tile Cholesky, MFMA GEMM modes, panel schemes, look-ahead, slab layout, triangular solves,
+LAUUM gradient, jitter ladder) are checked against the oracle in the ``-m "not gpu"`` suite as well.
+
+Test infrastructure only: it proves nothing about speed or about what the GPU executes (that is what ``-m gpu`` is for),
+the product binding cannot reach this library, and nothing here is ever timed or shipped.
+"""
+
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emu"))
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(f"_emu_{name}", os.path.join(HERE, f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from inject import installed
+
+    with installed() as lib:
+        yield lib
+
+
+@pytest.fixture(scope="module")
+def P(emu):
+    return _load("test_gpu_parity")
+
+
+@pytest.fixture(scope="module")
+def S(emu):
+    return _load("test_gpu_slab_layout")
+
+
+def test_cpu_build_exports_the_whole_c_abi(emu):
+    from battgp_amd import _lib
+
+    assert emu.bgp_version() >= 100
+    for name in _lib.SIGNATURES:
+        assert hasattr(emu, name)
+    assert os.path.dirname(emu._name).endswith(os.path.join("tests", "emu", "_build"))
+    assert _lib.LIB_PATH.endswith(os.path.join("battgp_amd", "libbattgp.so"))  # the product path is untouched
+
+
+@pytest.mark.parametrize("kid", [0, 1, 2, 3])
+def test_fill_kernel_vs_oracle(P, kid):
+    P.test_kernel_matrix_matches_oracle(kid, 37, 201)
+    P.test_kernel_matrix_matches_oracle(kid, 1, 1)
+
+
+def test_fill_generic_dims_and_unsorted_time(P):
+    P.test_kernel_matrix_generic_dims()
+    P.test_unsorted_time_column_takes_the_general_wiener_path()
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 300])
+def test_fit_predict_production_hyperparameters(P, n):
+    P.test_fit_predict_battgp_production_hyp(n)
+
+
+@pytest.mark.parametrize("kid", [1, 2, 3])
+def test_fit_predict_other_kernels(P, kid):
+    P.test_fit_predict_other_kernels(kid, 200)
+
+
+def test_reference_known_answers_and_golden_vectors(P, golden_dir):
+    P.test_reference_known_answers_on_gpu()
+    P.test_stgp_egp_golden_on_gpu(golden_dir)
+    P.test_golden_oracle_cases(golden_dir)
+
+
+def test_jitter_ladder_variance_clamp_refit(P):
+    P.test_jitter_ladder_and_not_psd()
+    P.test_variance_clamp_matches_gpytorch_min_variance()
+    P.test_refit_equals_fresh_fit()
+    P.test_fit_predict_with_jitter_retry()
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (65, 300), (300, 37)])
+def test_fused_equals_separate(P, n, m):
+    P.test_fit_predict_fused_equals_separate(n, m)
+
+
+@pytest.mark.parametrize("kid", [0, 1, 2, 3])
+def test_lml_gradient_vs_oracle(P, kid):
+    P.test_lml_gradient_matches_oracle(kid, 24)
+
+
+def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
+    """Several outer panels at a CPU-sized N (nb_outer = 128, N = 600): panel schemes 0 and 1, look-ahead off / depth 1 /
+    depth 2 / ordered, the column-slab layout, the LAUUM gradient and the explicit-inverse backward solve - the code
+    paths the GPU only reaches from N = 16 384 on with the default widths."""
+    from battgp_amd import synthetic
+    from battgp_amd.engine import ExactGPEngine
+    from oracle import kernels as K
+    from oracle.exact_gp import OracleGP, lml_and_grad
+
+    n = 600
+    x, y = synthetic.make_cell_data(n, seed=21)
+    xq = synthetic.make_query(x, 45)
+    for kid, hyp in ((K.KERNEL_BATTGP, synthetic.HYP_BATTGP), (K.KERNEL_MATERN32, synthetic.HYP_MATERN32)):
+        ref = OracleGP(kid, hyp, x, y).fit()
+        m_ref, v_ref = ref.predict(xq)
+        _, g_ref = lml_and_grad(kid, hyp, x, y)
+        outs = {}
+        for scheme in (0, 1):
+            for la in (0, 1, 2, 9):
+                e = ExactGPEngine(kid, hyp)
+                e.set_options(nb_outer=128, lookahead=la)
+                e.set_panel_scheme(scheme)
+                lml, mean, var = e.fit_predict(x, y, xq)
+                outs[(scheme, la)] = (lml, mean, var)
+                if la == 1:
+                    g = e.lml_grad()
+                    assert np.max(np.abs(g - g_ref) / np.abs(g_ref)) < 1e-7
+                    alpha = e.alpha()
+                    assert np.linalg.norm(alpha - ref.alpha) < 1e-4 * np.linalg.norm(ref.alpha)
+                    res = e.residuals(64)
+                    assert res[0] < 1e-7 and res[1] < 1e-12
+                e.close()
+            base = outs[(scheme, 0)]
+            for la in (1, 2, 9):  # look-ahead never changes a bit
+                assert outs[(scheme, la)][0] == base[0]
+                assert np.array_equal(outs[(scheme, la)][1], base[1]) and np.array_equal(outs[(scheme, la)][2], base[2])
+            assert abs(base[0] - ref.lml) < 1e-9 * abs(ref.lml)
+            assert np.linalg.norm(base[1] - m_ref) < 1e-8 * np.linalg.norm(m_ref)
+            assert np.max(np.abs(base[2] - v_ref)) < 1e-9 * np.max(np.abs(v_ref))
+        # the two schemes order their sums differently: agreement at rounding level
+        assert abs(outs[(0, 0)][0] - outs[(1, 0)][0]) < 1e-11 * abs(ref.lml)
+        # slab layout: bit-identical to the full square
+        e = ExactGPEngine(kid, hyp)
+        e.set_options(nb_outer=128)
+        e.set_panel_scheme(1)
+        e.set_layout(256)
+        lml_s, mean_s, var_s = e.fit_predict(x, y, xq)
+        g_s = e.lml_grad()
+        e.close()
+        assert lml_s == outs[(1, 1)][0] and np.array_equal(mean_s, outs[(1, 1)][1]) and np.array_equal(var_s, outs[(1, 1)][2])
+        assert np.max(np.abs(g_s - g_ref) / np.abs(g_ref)) < 1e-7
+
+
+def test_slab_layout_and_full_covariance(S):
+    S.test_slab_layout_bit_identical_to_full_square(0, 1000, 512, 512, True)
+    S.test_slab_width_must_match_the_panel_width()
+
+
+def test_predict_cov_and_errors(P):
+    P.test_errors_are_reported_not_crashed()
+    P.test_fit_predict_generic_input_dimension(3)
