@@ -1,0 +1,50 @@
+"""TEST INFRASTRUCTURE ONLY: one pass over the engine's code paths through the AddressSanitizer build of the CPU
+stand-in (tests/emu).  Run by tests/test_emu_kernels.py::test_address_sanitizer_pass in a child process that has the
+sanitizer runtime preloaded; every global / LDS / workspace access of the UNMODIFIED kernel sources is bounds-checked
+(device buffers are plain heap allocations there, LDS arrays are stack/static arrays of the block)."""
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+from inject import installed  # noqa: E402
+
+
+def main() -> int:
+    with installed(sanitize="asan"):
+        from battgp_amd import synthetic
+        from battgp_amd.engine import ExactGPEngine
+
+        for kid, hyp in ((0, synthetic.HYP_BATTGP), (2, synthetic.HYP_MATERN32)):
+            cases = ((1, 1, 0, 0, 1, 0), (65, 3, 0, 1, 1, 0), (333, 70, 128, 1, 1, 0), (333, 70, 128, 0, 2, 0), (400, 9, 128, 1, 1, 256))
+            for n, m, nb, scheme, la, slab in cases if kid == 0 else cases[2:3]:
+                x, y = synthetic.make_cell_data(n, seed=5)
+                xq = synthetic.make_query(x, m)
+                e = ExactGPEngine(kid, hyp)
+                if nb:
+                    e.set_options(nb_outer=nb, lookahead=la)
+                e.set_panel_scheme(scheme)
+                if slab:
+                    e.set_layout(slab)
+                lml, mean, var = e.fit_predict(x, y, xq)
+                assert np.isfinite(lml) and np.all(np.isfinite(mean)) and np.all(var > 0)
+                m2, v2 = e.predict(synthetic.make_query(x, m + 5))  # later prediction: separate query pass
+                assert np.all(np.isfinite(m2)) and np.all(v2 > 0)
+                g = e.lml_grad()
+                assert np.all(np.isfinite(g))
+                a = e.alpha()
+                assert np.all(np.isfinite(a))
+                r = e.residuals(16)
+                assert r[0] < 1e-6
+                e.refit(hyp)
+                e.close()
+    print("ASAN-PASS-DONE")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -23,25 +23,41 @@ def _compiler() -> str:
     return "clang++"
 
 
-def build(sanitize: bool = False, force: bool = False, verbose: bool = False) -> str:
+def sanitizer_runtime(kind: str = "asan") -> str:
+    """Path of the shared sanitizer runtime (to LD_PRELOAD into a python that loads the sanitized library)."""
+    name = {"asan": "libclang_rt.asan-x86_64.so", "ubsan": "libclang_rt.ubsan_standalone-x86_64.so"}[kind]
+    return subprocess.run([_compiler(), f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+
+
+def build(sanitize=False, force: bool = False, verbose: bool = False) -> str:
+    """``sanitize``: False, True / "ubsan" (UndefinedBehaviorSanitizer) or "asan" (AddressSanitizer; the fiber
+    switches are announced to it, LD_PRELOAD ``sanitizer_runtime("asan")`` into the loading process)."""
     os.makedirs(OUT_DIR, exist_ok=True)
-    lib = os.path.join(OUT_DIR, "libbattgp_emu_san.so" if sanitize else "libbattgp_emu.so")
+    kind = "asan" if sanitize == "asan" else ("ubsan" if sanitize else "")
+    lib = os.path.join(OUT_DIR, f"libbattgp_emu_{kind}.so" if kind else "libbattgp_emu.so")
     deps = SOURCES + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "bgp_internal.h"), os.path.join(ROOT, "include", "battgp.h")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(d) for d in deps):
         return lib
     objs = []
     flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-march=native", "-ffp-contract=fast", "-pthread", f"-I{HERE}", "-Wall",
              "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-unused-variable", "-Wno-unused-value"]
-    if sanitize:
+    if kind == "ubsan":
         flags += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"]
+    elif kind == "asan":
+        flags += ["-fsanitize=address", "-fno-omit-frame-pointer"]
+        flags[flags.index("-O2")] = "-O1"
     for src in SOURCES:
-        obj = os.path.join(OUT_DIR, os.path.basename(src) + (".san.o" if sanitize else ".o"))
+        obj = os.path.join(OUT_DIR, os.path.basename(src) + (f".{kind}.o" if kind else ".o"))
         cmd = [_compiler(), "-x", "c++", *flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [_compiler(), "-shared", "-pthread", *(["-fsanitize=undefined"] if sanitize else []), *objs, "-o", lib]
+    san_link = []
+    if kind:  # the sanitizer runtime as a shared object next to the compiler, found through an rpath
+        rt_dir = os.path.dirname(sanitizer_runtime(kind))
+        san_link = ["-fsanitize=address" if kind == "asan" else "-fsanitize=undefined", "-shared-libsan", f"-Wl,-rpath,{rt_dir}"]
+    cmd = [_compiler(), "-shared", "-pthread", *san_link, *objs, "-o", lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -51,4 +67,4 @@ def build(sanitize: bool = False, force: bool = False, verbose: bool = False) ->
 if __name__ == "__main__":
     import sys
 
-    print(build(sanitize="--sanitize" in sys.argv, force=True, verbose=True))
+    print(build(sanitize="asan" if "--asan" in sys.argv else ("--sanitize" in sys.argv), force=True, verbose=True))

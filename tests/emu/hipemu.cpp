@@ -8,6 +8,7 @@
 // with a message instead of hanging.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <pthread.h>
 #include <sys/mman.h>
 
 #include <atomic>
@@ -38,6 +39,13 @@ hipemu_switch:
 .size hipemu_switch, .-hipemu_switch
 )");
 
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
 namespace hipemu {
 
 double now_ms() {
@@ -53,6 +61,8 @@ enum State { READY = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
 
 struct Fiber {
   void* sp;
+  void* asan_fake = nullptr;  // AddressSanitizer's fake-stack handle while the fiber is switched out
+  const void* stack_lo = nullptr;
   Ctx ctx;
   int lin, lane, wave;
   State state;
@@ -73,6 +83,9 @@ struct Block {
   uint64_t gen = 0;
   int orv[2] = {0, 0};
   void* sched_sp = nullptr;
+  void* sched_fake = nullptr;
+  const void* sched_lo = nullptr;  // bounds of the scheduler's (the OS thread's) stack, for AddressSanitizer
+  size_t sched_size = 0;
   Fiber* cur = nullptr;
   const std::function<void()>* body = nullptr;
   char* stacks = nullptr;
@@ -80,10 +93,24 @@ struct Block {
 
 thread_local Block* t_blk = nullptr;
 
-void yield_to_scheduler() {
+// AddressSanitizer must be told about every stack switch (it tracks the bounds of the running stack)
+inline void asan_leave(void** fake_save, const void* to_lo, size_t to_size) {
+#ifdef HIPEMU_ASAN
+  __sanitizer_start_switch_fiber(fake_save, to_lo, to_size);
+#endif
+}
+inline void asan_enter(void* fake_saved) {
+#ifdef HIPEMU_ASAN
+  __sanitizer_finish_switch_fiber(fake_saved, nullptr, nullptr);
+#endif
+}
+
+void yield_to_scheduler(bool dying = false) {
   Block* b = t_blk;
   Fiber* f = b->cur;
+  asan_leave(dying ? nullptr : &f->asan_fake, b->sched_lo, b->sched_size);
   hipemu_switch(&f->sp, b->sched_sp);
+  asan_enter(f->asan_fake);
 }
 
 void release_wave_if_complete(Wave& w) {
@@ -103,6 +130,7 @@ void release_block_if_complete(Block* b) {
 void fiber_main() {
   Block* b = t_blk;
   Fiber* f = b->cur;
+  asan_enter(nullptr);
   (*b->body)();
   // thread leaves the kernel: it no longer takes part in any rendezvous
   f->state = DONE;
@@ -111,7 +139,7 @@ void fiber_main() {
   --b->live;
   release_wave_if_complete(w);
   release_block_if_complete(b);
-  yield_to_scheduler();
+  yield_to_scheduler(true);
   fprintf(stderr, "hipemu: finished fiber resumed\n");
   abort();
 }
@@ -164,8 +192,22 @@ void run_block(Block* b, dim3 grid, dim3 block, dim3 bid, const std::function<vo
     *--sp = reinterpret_cast<void*>(&fiber_main);     // popped by `ret`
     for (int r = 0; r < 6; ++r) *--sp = nullptr;      // rbp rbx r12 r13 r14 r15
     f.sp = sp;
+    f.stack_lo = top - STACK;
+    f.asan_fake = nullptr;
   }
   t_blk = b;
+#ifdef HIPEMU_ASAN
+  if (b->sched_lo == nullptr) {
+    pthread_attr_t attr;
+    pthread_getattr_np(pthread_self(), &attr);
+    void* lo = nullptr;
+    size_t sz = 0;
+    pthread_attr_getstack(&attr, &lo, &sz);
+    pthread_attr_destroy(&attr);
+    b->sched_lo = lo;
+    b->sched_size = sz;
+  }
+#endif
   while (b->live > 0) {
     bool progressed = false;
     for (int t = 0; t < nt; ++t) {
@@ -176,7 +218,9 @@ void run_block(Block* b, dim3 grid, dim3 block, dim3 bid, const std::function<vo
       f.state = READY;
       b->cur = &f;
       g_ctx = &f.ctx;
+      asan_leave(&b->sched_fake, f.stack_lo, STACK);
       hipemu_switch(&b->sched_sp, f.sp);
+      asan_enter(b->sched_fake);
       progressed = true;
     }
     if (!progressed) {

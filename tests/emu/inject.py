@@ -19,7 +19,7 @@ def load_emu(sanitize: bool = False) -> C.CDLL:
 
     from battgp_amd import _lib
 
-    key = "san" if sanitize else "plain"
+    key = str(sanitize) if sanitize else "plain"
     if key not in _cache:
         lib = C.CDLL(build_emu.build(sanitize=sanitize))
         for name, (res, args) in _lib.SIGNATURES.items():

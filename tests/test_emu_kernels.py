@@ -162,3 +162,22 @@ def test_slab_layout_and_full_covariance(S):
 def test_predict_cov_and_errors(P):
     P.test_errors_are_reported_not_crashed()
     P.test_fit_predict_generic_input_dimension(3)
+
+
+def test_address_sanitizer_pass():
+    """The GPU pool offers no address sanitizer; the CPU build does.  One pass over the engine's code paths (several
+    outer panels, both panel schemes, slab layout, later predictions, gradient, backward solve) through the
+    AddressSanitizer build, in a child process with the sanitizer runtime preloaded: every global-memory, workspace and
+    LDS-array access of the kernel sources is bounds-checked."""
+    import subprocess
+
+    import build_emu
+
+    build_emu.build(sanitize="asan")
+    rt = build_emu.sanitizer_runtime("asan")
+    if not os.path.exists(rt):
+        pytest.skip("no shared AddressSanitizer runtime next to the host clang")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "asan_workload.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "ASAN-PASS-DONE" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
