@@ -135,21 +135,24 @@ struct PhaseTimer {
 // `A` is the origin of the panel's slab (or of a stand-alone panel), K0 the panel's first column
 // relative to it and `gofs` the global index of that origin (tile inverses and the failing-minor
 // report are indexed globally).
+// `slim`: the chain kernels that fit next to two resident trailing-update workgroups (bgp_linalg.hip); same results
 int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t nrows, int64_t lda, double* inv, int* dinfo,
-                 int64_t K0, int64_t nbk, int64_t gofs = 0) {
+                 int64_t K0, int64_t nbk, int64_t gofs = 0, bool slim = false) {
   for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
     double* inv_j = inv + ((j + gofs) / BGP_IB) * (BGP_IB * BGP_IB);
-    int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)(j + gofs), 64);
+    int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)(j + gofs), slim ? 1 : 0);
     if (rc) return rc;
     const int64_t rows_below = nrows - (j + BGP_IB);
     if (rows_below > 0) {
       double* A21 = A + (j + BGP_IB) + j * lda;
-      rc = launch_gemm_nt(h, st, 1, 64, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0, dinfo);
+      rc = slim ? launch_chain_gemm_slim(h, st, 1, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, 0, dinfo)
+                : launch_gemm_nt(h, st, 1, 64, A21, lda, A21, lda, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0, dinfo);
       if (rc) return rc;
       const int64_t ncols = K0 + nbk - (j + BGP_IB);
       if (ncols > 0) {
-        rc = launch_gemm_nt(h, st, 0, 128, A + (j + BGP_IB) + (j + BGP_IB) * lda, lda, A21, lda, A21, lda,
-                            rows_below, ncols, BGP_IB, 1, dinfo);
+        double* A22 = A + (j + BGP_IB) + (j + BGP_IB) * lda;
+        rc = slim ? launch_chain_gemm_slim(h, st, 0, A22, lda, A21, lda, A21, lda, rows_below, ncols, 1, dinfo)
+                  : launch_gemm_nt(h, st, 0, 128, A22, lda, A21, lda, A21, lda, rows_below, ncols, BGP_IB, 1, dinfo);
         if (rc) return rc;
       }
     }
@@ -283,7 +286,8 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   if (V.W < n && (V.W % NB) != 0)
     return bgp_fail(h, -1, "slab width %lld is not a multiple of nb_outer=%lld", (long long)V.W, (long long)NB);
   // lookahead: bits 0-2 = depth d (0 = off), bit 3 = order the panel stream's updates before rest(k),
-  // bit 4 = no atomic-accumulate epilogue (ablation)
+  // bit 4 = no atomic-accumulate epilogue (ablation), bit 5 = slim chain kernels for a diagonal-block chain that
+  // runs underneath a trailing update (they fit beside its two workgroups per CU instead of queueing for a slot)
   const int depth_req = h->lookahead & 7;
   const bool la = depth_req != 0 && n > NB;  // from two panels on
   const int depth = la ? (depth_req > BGP_MAX_WBUF - 1 ? BGP_MAX_WBUF - 1 : depth_req) : 0;
@@ -360,8 +364,10 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
       const int64_t ldk = V.ld(K0), ldd = 2 * NB;
       double* Akk = V.at(K0, K0);
       if ((rc = launch_diag_in(h, sp, Akk, ldk, h->dD, ldd, (int)nbk))) return rc;
-      if ((rc = factor_panel(h, sp, h->dD, 2 * nbk, ldd, inv, dinfo, 0, nbk, K0))) return rc;
-      if ((rc = launch_diag_out(h, sp, h->dD, ldd, Akk, ldk, h->dLinv, NB, (int)nbk))) return rc;
+      // panel 0 has no trailing update above it: nothing to fit beside
+      const bool slim = la && step > 0 && (h->lookahead & 32) != 0;
+      if ((rc = factor_panel(h, sp, h->dD, 2 * nbk, ldd, inv, dinfo, 0, nbk, K0, slim))) return rc;
+      if ((rc = launch_diag_out(h, sp, h->dD, ldd, Akk, ldk, h->dLinv, NB, (int)nbk, slim ? 1 : 0))) return rc;
       const int64_t rows_below = nrows - K1;
       if (rows_below > 0) {
         double* W = h->dW[step % nbuf];
@@ -1523,7 +1529,7 @@ int bgp_factor_pack_panel_async_dev(bgp_handle* h, double* panel_dev, int64_t ld
   if ((rc = launch_diag_in(h, st, panel_dev, ld, h->dD, ldd, nbk))) return rc;
   for (int64_t j = 0; j < nbk; j += BGP_IB) {  // factor_panel with a global report offset but panel-local inverses
     double* inv_j = inv_dev + (j / BGP_IB) * (BGP_IB * BGP_IB);
-    if ((rc = launch_potrf_tile(h, st, h->dD + j + j * ldd, ldd, inv_j, h->dinfo, (int)(j + gofs), 64))) return rc;
+    if ((rc = launch_potrf_tile(h, st, h->dD + j + j * ldd, ldd, inv_j, h->dinfo, (int)(j + gofs)))) return rc;
     const int64_t rows_below = 2 * (int64_t)nbk - (j + BGP_IB);
     double* A21 = h->dD + (j + BGP_IB) + j * ldd;
     if ((rc = launch_gemm_nt(h, st, 1, 64, A21, ldd, A21, ldd, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0, h->dinfo))) return rc;

@@ -146,11 +146,15 @@ int launch_trinv_panels(bgp_handle* h, hipStream_t st, const SlabView& L, const 
                         int64_t n, int NB);
 int launch_diag_in(bgp_handle* h, hipStream_t st, const double* Akk, int64_t lda, double* D, int64_t ldd, int nbk);
 int launch_diag_out(bgp_handle* h, hipStream_t st, const double* D, int64_t ldd, double* Akk, int64_t lda,
-                    double* Linv, int64_t ldl, int nbk);
+                    double* Linv, int64_t ldl, int nbk, int slim = 0);
 int launch_copy_panel(bgp_handle* h, hipStream_t st, const double* src, int64_t lds_, double* dst, int64_t ldd,
                       int64_t rows, int ncols);
+// slim != 0 (here and in launch_diag_out): the variants that fit next to two resident trailing-update workgroups
+// (<= 64 VGPRs, <= 12 KB LDS; bgp_linalg.hip "slim chain kernels"); bit-identical results
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv,
-                      int* info, int col0, int nvalid);
+                      int* info, int col0, int slim = 0);
+int launch_chain_gemm_slim(bgp_handle* h, hipStream_t st, int mode, double* C, int64_t ldc, const double* A, int64_t lda,
+                           const double* B, int64_t ldb, int64_t m, int64_t n, int lower, const int* abort_flag);
 int launch_fit_scalars(bgp_handle* h, hipStream_t st, const SlabView& A, const double* z,
                        int64_t ldz, int64_t n, double* out2);
 int launch_aug_rows(bgp_handle* h, hipStream_t st, const double* y, int64_t n, double* Aaug, int64_t lda,

@@ -14,6 +14,12 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// register budget of a kernel = 512 / n VGPRs per lane (a host build of these sources for tests defines it away)
+#ifndef BGP_WAVES_PER_EU
+#define BGP_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#define BGP_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+
 namespace {
 
 constexpr int BK = 16;  // k-depth of one LDS stage
@@ -301,12 +307,16 @@ __device__ __forceinline__ double rsqrt_newton(double p) {
 // diagonal) on exit; every wave executes exactly 64 barriers, in three phases: (A) steps j < C0 update
 // all 16 columns, (B) the 16 steps that own the pivot column, (C) steps j >= C0 + 16 only keep the
 // barrier count
-template <int W>
-__device__ __forceinline__ void chol_cols(double (*s)[64], double (*colbuf)[64], int* sfail, int lane) {
+// LEAN: L(c, j) of the own columns comes out of the one LDS read of column j by v_readlane (scalar registers)
+// instead of 16 more uniform LDS reads (vector registers): same values, 32 VGPRs fewer alive
+struct NoColumnHook {
+  __device__ __forceinline__ void operator()(int, double, double) const {}
+};
+// `done(j, col, d)`: called by the owner wave when column j is final (col = L(lane, j) with d on the diagonal)
+template <int W, bool LEAN = false, typename Done = NoColumnHook>
+__device__ __forceinline__ void chol_cols_reg(double (&a)[16], double (*colbuf)[64], int* sfail, int lane,
+                                              Done done = Done()) {
   constexpr int NC = 16, C0 = NC * W;
-  double a[NC];
-#pragma unroll
-  for (int cc = 0; cc < NC; ++cc) a[cc] = s[C0 + cc][lane];
   // (A) a rolled loop is fine here: every register index is static
 #pragma unroll 1
   for (int j = 0; j < C0; ++j) {
@@ -314,7 +324,7 @@ __device__ __forceinline__ void chol_cols(double (*s)[64], double (*colbuf)[64],
     const double* col = colbuf[j & 1];
     const double lij = col[lane];
 #pragma unroll
-    for (int cc = 0; cc < NC; ++cc) a[cc] = __builtin_fma(-lij, col[C0 + cc], a[cc]);
+    for (int cc = 0; cc < NC; ++cc) a[cc] = __builtin_fma(-lij, LEAN ? readlane_d(lij, C0 + cc) : col[C0 + cc], a[cc]);
   }
   // (B)
 #pragma unroll
@@ -329,6 +339,7 @@ __device__ __forceinline__ void chol_cols(double (*s)[64], double (*colbuf)[64],
     a[jl] = (lane == j) ? d : lij;
     colbuf[j & 1][lane] = lij;
     __syncthreads();
+    done(j, a[jl], d);
     // my own columns right of j: L(c, j) straight from the owner's registers (no LDS round trip on the
     // critical path of the next pivot)
 #pragma unroll
@@ -337,6 +348,15 @@ __device__ __forceinline__ void chol_cols(double (*s)[64], double (*colbuf)[64],
   // (C)
 #pragma unroll 1
   for (int j = C0 + NC; j < 64; ++j) __syncthreads();
+}
+
+template <int W>
+__device__ __forceinline__ void chol_cols(double (*s)[64], double (*colbuf)[64], int* sfail, int lane) {
+  constexpr int NC = 16, C0 = NC * W;
+  double a[NC];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) a[cc] = s[C0 + cc][lane];
+  chol_cols_reg<W>(a, colbuf, sfail, lane);
 #pragma unroll
   for (int cc = 0; cc < NC; ++cc) s[C0 + cc][lane] = (C0 + cc <= lane) ? a[cc] : 0.0;
 }
@@ -402,6 +422,196 @@ __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(double* __restrict__
     case 2: inv_cols<2>(s, inv, lane); break;
     default: inv_cols<3>(s, inv, lane); break;
   }
+}
+
+// ---- "slim" chain kernels: made to fit NEXT TO two resident trailing-update workgroups ----------------
+// gemm_nt_kernel<128,128,2> holds 224 VGPRs per wave and 73 728 B of LDS per workgroup, two workgroups per CU: what a
+// CU has left while `rest(k)` runs is 64 VGPRs per SIMD lane and <= 16 KB of LDS (tools/kernel_resources.py).  The
+// chain kernels above (78-117 VGPRs, 33-41 KB) cannot be placed until a trailing-update workgroup retires - a whole
+// 128 x 128 x NB tile, 110-250 us - and that wait, not their arithmetic, is what the panel stream spends its time on
+// underneath a saturating update.  The variants below do the same arithmetic IN THE SAME ORDER (bit-identical results)
+// inside <= 64 VGPRs and <= 12 KB of LDS, so the dispatcher can place them at once beside the running update.
+// Stand-alone they are slower (no LDS tile for the Cholesky, 8-deep single-buffered GEMM stages), so the driver only
+// uses them for the diagonal-block chain of a panel that is factored underneath a trailing update.
+
+// pins a wave-uniform pointer in scalar registers (the intrinsic also keeps the compiler from folding the lane offset
+// into it) and marks it as a global-memory address: accesses become  global_load/store v, v_lane_offset, s[base]  -
+// ONE 32-bit offset VGPR for all columns instead of a 64-bit address per column
+typedef BGP_GLOBAL_AS double gmem_double;
+__device__ __forceinline__ gmem_double* scalar_ptr(const double* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (gmem_double*)(((uint64_t)hi << 32) | lo);
+}
+
+// wave W of the slim tile kernel: columns 16W..16W+15 of the tile in registers (lane = row).  A column leaves the
+// registers the moment it is final: to global memory (the factor), and - columns 16..63, strictly below the diagonal,
+// packed: 1128 doubles - to LDS for the inverse; columns 0..15 are re-read from global memory by the inverse
+// (written by this workgroup, read behind a barrier: workgroup-scope coherent through the CU's own L1 / L2).
+constexpr int SLIM_LQ = 1128;  // sum_{c = 16}^{63} (63 - c)
+__device__ __forceinline__ constexpr int slim_lq_off(int c) {  // first entry (row c + 1) of column c >= 16
+  return (c - 16) * 47 - ((c - 16) * (c - 17)) / 2;            // sum_{t = 16}^{c - 1} (63 - t)
+}
+
+template <int W>
+__device__ __forceinline__ void potrf_slim_body(double* __restrict__ Ajj, int64_t lda, double* __restrict__ inv,
+                                                double (*colbuf)[64], double* lq, double* srd, int* sfail,
+                                                int* __restrict__ info, int col0, int lane) {
+  constexpr int NC = 16, C0 = NC * W;
+  const unsigned ulane = (unsigned)lane;
+  {
+    double a[NC];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) a[cc] = scalar_ptr(Ajj + (int64_t)(C0 + cc) * lda)[ulane];  // 512 B per column, coalesced
+    chol_cols_reg<W, true>(a, colbuf, sfail, lane, [&](int j, double col, double d) {
+      gmem_double* colp = scalar_ptr(Ajj + (int64_t)j * lda);  // (formed by the whole wave, outside the lane condition)
+      if (lane >= j) colp[ulane] = col;
+      if (j >= 16 && lane > j) lq[slim_lq_off(j) + lane - j - 1] = col;
+      if (lane == j) srd[j] = 1.0 / d;
+    });
+  }
+  __syncthreads();
+  if (W == 0 && lane == 0 && *sfail != 0) atomicCAS(info, 0, col0 + *sfail);
+  // X = L^-1: the forward substitution of inv_cols (column c = W + 4 t of X belongs to wave W), every step with the
+  // same operations in the same order; a column that is not active yet (c > p) still holds e_c, for which a step is
+  // exactly the identity (0 * f = 0, x - lm * 0 = x), so the rolled loops need no per-column condition
+  double x[NC];
+  auto step = [&](int p, double lcol, auto ncols) {
+    constexpr int NCOL = decltype(ncols)::value;
+    const double f = (lane == p) ? srd[p] : 1.0;
+    const double lm = (lane > p) ? lcol : 0.0;  // L(lane, p); zero on and above the diagonal
+#pragma unroll
+    for (int cc = 0; cc < NCOL; ++cc) {
+      x[cc] *= f;
+      const double xpc = readlane_d(x[cc], p);
+      x[cc] = __builtin_fma(-lm, xpc, x[cc]);
+    }
+  };
+  // steps 0..15 only concern the columns c < 16 of X (four per wave) and take their columns of L from global memory,
+  // four loads in flight ahead of the four steps being applied (rolled loops: the unrolled form keeps the operands of
+  // many steps alive at once and spills)
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) x[cc] = (lane == W + 4 * cc) ? 1.0 : 0.0;
+  {
+    double g[4], gn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[t] = scalar_ptr(Ajj + (int64_t)t * lda)[ulane];
+#pragma unroll 1
+    for (int grp = 0; grp < 4; ++grp) {
+      const int nxt = grp < 3 ? 4 * grp + 4 : 0;  // (the last group re-reads columns 0..3: harmless, keeps the loop uniform)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) gn[t] = scalar_ptr(Ajj + (int64_t)(nxt + t) * lda)[ulane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) step(4 * grp + t, g[t], std::integral_constant<int, 4>{});
+#pragma unroll
+      for (int t = 0; t < 4; ++t) g[t] = gn[t];
+    }
+  }
+  // steps 16..63: all sixteen columns, L from LDS
+#pragma unroll
+  for (int cc = 4; cc < NC; ++cc) x[cc] = (lane == W + 4 * cc) ? 1.0 : 0.0;
+#pragma unroll 1
+  for (int p = 16; p < 64; ++p) {
+    const int off = (p - 16) * 47 - ((p - 16) * (p - 17)) / 2;
+    step(p, lane > p ? lq[off + lane - p - 1] : 0.0, std::integral_constant<int, NC>{});
+  }
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) scalar_ptr(inv + (W + 4 * cc) * 64)[ulane] = x[cc];
+}
+
+__global__ __launch_bounds__(256) BGP_WAVES_PER_EU(8)
+void potrf_tile_slim_kernel(double* __restrict__ Ajj, int64_t lda, double* __restrict__ inv, int* __restrict__ info,
+                            int col0) {
+  __shared__ double colbuf[2][64];  // the scaled pivot column of the current step
+  __shared__ double lq[SLIM_LQ];    // columns 16..63 of L, rows below the diagonal, packed: the inverse reads them
+  __shared__ double srd[64];        // 1 / L_pp
+  __shared__ int sfail;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (*info != 0) return;
+  if (tid == 0) sfail = 0;
+  __syncthreads();
+  switch (wave) {
+    case 0: potrf_slim_body<0>(Ajj, lda, inv, colbuf, lq, srd, &sfail, info, col0, lane); break;
+    case 1: potrf_slim_body<1>(Ajj, lda, inv, colbuf, lq, srd, &sfail, info, col0, lane); break;
+    case 2: potrf_slim_body<2>(Ajj, lda, inv, colbuf, lq, srd, &sfail, info, col0, lane); break;
+    default: potrf_slim_body<3>(Ajj, lda, inv, colbuf, lq, srd, &sfail, info, col0, lane); break;
+  }
+}
+
+// The k = 64 products of the chain on 64 x 64 tiles:  MODE 0  C -= A B^T (`lower`: tiles with ti >= tj only),
+// MODE 1  C = A B^T (C may alias A: TRSM by the inverted tile).  Same fragment layout and the same order of MFMAs
+// over k as gemm_nt_kernel<64, 64, MODE> (bit-identical), but 8-deep single-buffered stages: 10 KB of LDS.
+template <int MODE>
+__global__ __launch_bounds__(256) BGP_WAVES_PER_EU(8)
+void chain_gemm_slim_kernel(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
+                            int64_t m, int64_t n, int lower, const int* __restrict__ abort_flag) {
+  constexpr int T = 64, SBK = 8, LDS_S = T + 16, KTOT = 64;
+  __shared__ __attribute__((aligned(16))) double sA[SBK][LDS_S];
+  __shared__ __attribute__((aligned(16))) double sB[SBK][LDS_S];
+  const int ti = (int)blockIdx.x, tj = (int)blockIdx.y;  // 2-D grid: tile indices arrive in scalar registers
+  if ((lower & 1) && ti < tj) return;
+  if (abort_flag != nullptr && *abort_flag != 0) return;
+  const int64_t i0 = (int64_t)ti * T, j0 = (int64_t)tj * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 1, wj = wave >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // staging: one double2 of A and one of B per thread and stage (rows 2 (tid % 32).., k column tid / 32)
+  const int rs = (tid & 31) * 2, cs = tid >> 5;
+  const double* gA = A + ((i0 + rs) < m ? (i0 + rs) : 0) + (int64_t)cs * lda;  // out-of-range rows: any valid address
+  const double* gB = B + ((j0 + rs) < n ? (j0 + rs) : 0) + (int64_t)cs * ldb;  // (they only reach unwritten outputs)
+  constexpr int NEG = (MODE == 0) ? 1 : 0;
+  // C(i, j) of lane (l15, l4), register r of MFMA tile (a, b):  i = i0 + wi 32 + b 16 + l15,  j = j0 + wj 32 + a 16 + l4 + 4 r
+  // = a wave-uniform base (scalar registers) + ONE 32-bit lane offset: sixteen 64-bit addresses would not fit the budget
+  const unsigned coff = (unsigned)((wi * 32 + l15) + (int64_t)(wj * 32 + l4) * ldc);
+  const bool i_in[2] = {i0 + wi * 32 + l15 < m, i0 + wi * 32 + 16 + l15 < m};
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + wj * 32 + a * 16 + l4 + 4 * r;
+        gmem_double* cp = scalar_ptr(C + (i0 + b * 16) + (j0 + a * 16 + 4 * r) * ldc);
+        acc[a][b][r] = (MODE == 0 && i_in[b] && j < n) ? cp[coff] : 0.0;
+      }
+  double2 ra = *reinterpret_cast<const double2*>(gA), rb = *reinterpret_cast<const double2*>(gB);
+  const int ibase = wi * 32 + l15, jbase = wj * 32 + l15;
+#pragma unroll 1
+  for (int kt = 0; kt < KTOT / SBK; ++kt) {
+    __syncthreads();  // the fragments of the previous stage have been read
+    *reinterpret_cast<double2*>(&sA[cs][rs]) = ra;
+    *reinterpret_cast<double2*>(&sB[cs][rs]) = rb;
+    if (kt + 1 < KTOT / SBK) {
+      ra = *reinterpret_cast<const double2*>(gA + (int64_t)(kt + 1) * SBK * lda);
+      rb = *reinterpret_cast<const double2*>(gB + (int64_t)(kt + 1) * SBK * ldb);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < SBK / 4; ++kk) {
+      const int pp = kk * 4 + l4;
+      double fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = sB[pp][jbase + a * 16];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = sA[pp][ibase + b * 16];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, NEG);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + wj * 32 + a * 16 + l4 + 4 * r;
+        gmem_double* cp = scalar_ptr(C + (i0 + b * 16) + (j0 + a * 16 + 4 * r) * ldc);
+        if (i_in[b] && j < n) cp[coff] = acc[a][b][r];
+      }
 }
 
 // ---- explicit inverses of ALL diagonal panel blocks of a factor, in one launch ---------------------
@@ -735,23 +945,26 @@ __global__ __launch_bounds__(256) void diag_in_kernel(const double* __restrict__
     D[r + (int64_t)c * ldd] = (r < nbk) ? Akk[r + (int64_t)c * lda] : ((r - nbk == c) ? 1.0 : 0.0);
 }
 
-// Akk (lower triangle) <- L_kk;  Linv[j + kk ldl] = (L^-T)[kk, j] = D[nbk + kk, j]  (LDS-tiled transpose)
+// Akk (lower triangle) <- L_kk;  Linv[j + kk ldl] = (L^-T)[kk, j] = D[nbk + kk, j]  (LDS-tiled transpose).
+// T = 64 (33 KB of LDS) or, next to a running trailing update, T = 32 (8.4 KB: fits what two of its workgroups leave).
+template <int T>
 __global__ __launch_bounds__(256) void diag_out_kernel(const double* __restrict__ D, int64_t ldd,
                                                        double* __restrict__ Akk, int64_t lda,
                                                        double* __restrict__ Linv, int64_t ldl, int nbk) {
-  __shared__ double t[64][65];
-  const int bi = blockIdx.x * 64, bj = blockIdx.y * 64;  // tile (rows bi.., cols bj..) of D / Akk
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  if (bi >= bj) {
-    for (int cc = ty; cc < 64; cc += 4) {
+  __shared__ double t[T][T + 1];
+  constexpr int STEP = 256 / T;
+  const int bi = blockIdx.x * T, bj = blockIdx.y * T;  // tile (rows bi.., cols bj..) of D / Akk
+  const int tx = threadIdx.x % T, ty = threadIdx.x / T;
+  if (bi + T > bj) {
+    for (int cc = ty; cc < T; cc += STEP) {
       const int r = bi + tx, c = bj + cc;
       if (r >= c) Akk[r + (int64_t)c * lda] = D[r + (int64_t)c * ldd];
     }
   }
   // R tile (rows kk = bi.., cols j = bj..) -> Linv tile (rows j = bj.., cols kk = bi..)
-  for (int cc = ty; cc < 64; cc += 4) t[cc][tx] = D[(nbk + bi + tx) + (int64_t)(bj + cc) * ldd];
+  for (int cc = ty; cc < T; cc += STEP) t[cc][tx] = D[(nbk + bi + tx) + (int64_t)(bj + cc) * ldd];
   __syncthreads();
-  for (int cc = ty; cc < 64; cc += 4) Linv[(bj + tx) + (int64_t)(bi + cc) * ldl] = t[tx][cc];
+  for (int cc = ty; cc < T; cc += STEP) Linv[(bj + tx) + (int64_t)(bi + cc) * ldl] = t[tx][cc];
 }
 
 // dst[r + c ldd] = src[r + c lds] for r < rows (even), c < ncols: copy-back of the solved panel
@@ -810,9 +1023,13 @@ int launch_diag_in(bgp_handle* h, hipStream_t st, const double* Akk, int64_t lda
 }
 
 int launch_diag_out(bgp_handle* h, hipStream_t st, const double* D, int64_t ldd, double* Akk, int64_t lda,
-                    double* Linv, int64_t ldl, int nbk) {
-  hipLaunchKernelGGL(diag_out_kernel, dim3((unsigned)(nbk / 64), (unsigned)(nbk / 64)), dim3(256), 0, st, D, ldd, Akk,
-                     lda, Linv, ldl, nbk);
+                    double* Linv, int64_t ldl, int nbk, int slim) {
+  if (slim)
+    hipLaunchKernelGGL((diag_out_kernel<32>), dim3((unsigned)(nbk / 32), (unsigned)(nbk / 32)), dim3(256), 0, st, D, ldd,
+                       Akk, lda, Linv, ldl, nbk);
+  else
+    hipLaunchKernelGGL((diag_out_kernel<64>), dim3((unsigned)(nbk / 64), (unsigned)(nbk / 64)), dim3(256), 0, st, D, ldd,
+                       Akk, lda, Linv, ldl, nbk);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }
@@ -877,8 +1094,31 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
 }
 
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv, int* info,
-                      int col0, int /*nvalid*/) {
-  hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
+                      int col0, int slim) {
+  if (slim)
+    hipLaunchKernelGGL(potrf_tile_slim_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
+  else
+    hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+// the k = 64 products of the panel chain with the slim kernels (<= 64 VGPRs, 10 KB LDS): mode 0  C -= A B^T
+// (lower: tiles touching i >= j only), mode 1  C = A B^T (C may alias A)
+int launch_chain_gemm_slim(bgp_handle* h, hipStream_t st, int mode, double* C, int64_t ldc, const double* A, int64_t lda,
+                           const double* B, int64_t ldb, int64_t m, int64_t n, int lower, const int* abort_flag) {
+  if (m <= 0 || n <= 0) return 0;
+  if ((m & 1) || (n & 1) || (lda & 1) || (ldb & 1) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
+    return bgp_fail(h, -1, "chain_gemm_slim: m, n, lda, ldb must be even and the operands 16-byte aligned");
+  const int64_t nti = (m + 63) / 64, ntj = (n + 63) / 64;
+  if (nti > 0x7fffffffLL || ntj > 65535) return bgp_fail(h, -1, "chain_gemm_slim: grid too large");
+  const dim3 grid((unsigned)nti, (unsigned)ntj);
+  if (mode == 0)
+    hipLaunchKernelGGL((chain_gemm_slim_kernel<0>), grid, dim3(256), 0, st, C, ldc, A, lda, B, ldb, m, n, lower, abort_flag);
+  else if (mode == 1)
+    hipLaunchKernelGGL((chain_gemm_slim_kernel<1>), grid, dim3(256), 0, st, C, ldc, A, lda, B, ldb, m, n, lower, abort_flag);
+  else
+    return bgp_fail(h, -1, "chain_gemm_slim: unsupported mode %d", mode);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

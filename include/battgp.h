@@ -103,7 +103,10 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
  *                    applies panel k to the panels from k+d+1 on (d > 1 measured slower: the panel stream is
  *                    the critical path); +8: the panel stream's updates are ordered before the main
  *                    stream's (per-launch timings do not overlap, ~1 % slower); +16: trailing updates
- *                    without the atomic-accumulate epilogue (ablation).  Bit-identical results for all. */
+ *                    without the atomic-accumulate epilogue (ablation); +32: the diagonal-block chain of a panel that
+ *                    is factored underneath a trailing update uses kernels sized to fit NEXT TO the update's two
+ *                    workgroups per CU (<= 64 VGPRs, <= 12 KB LDS) instead of queueing for a CU slot.
+ *                    Bit-identical results for all. */
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
 
 /* Panel scheme of the blocked Cholesky (speed only; both are exact-Cholesky algebra).

@@ -25,6 +25,8 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define BGP_WAVES_PER_EU(n)  // the kernel sources' register-budget attribute means nothing on the host ...
+#define BGP_GLOBAL_AS         // ... and neither does the global address space
 #define __shared__ static thread_local
 
 struct dim3 {

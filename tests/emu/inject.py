@@ -96,6 +96,8 @@ def fake_cuda_tensors():
     torch.cuda.empty_cache = lambda: None
     torch.cuda.mem_get_info = lambda *a, **k: (48 << 30, 64 << 30)
     torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.is_current_stream_capturing = lambda: False  # torch.optim's capture health check
+    torch.Tensor.is_cuda = property(lambda self: True)      # "device" tensors live on the host here
 
     class _Stream:
         def __init__(self, *a, **k):

@@ -490,6 +490,33 @@ def test_panel_schemes_agree_and_match_oracle(kid, n, nb):
     assert np.max(np.abs(out[1][2] - v_ref) / K.kernel_diag(kid, hyp, xq)) < 1e-9
 
 
+@pytest.mark.parametrize("kid", [K.KERNEL_BATTGP, K.KERNEL_MATERN32])
+@pytest.mark.parametrize("n,nb", [(700, 128), (3001, 512), (20000, 512)])
+def test_slim_chain_kernels_are_bit_identical(kid, n, nb):
+    """lookahead bit 5: the diagonal-block chain of every panel after the first runs on the kernels sized to fit next
+    to the trailing update's workgroups (potrf_tile_slim, chain_gemm_slim, 32-wide diag_out) - same arithmetic in the
+    same order, so factor, LML, posterior and tile inverses are identical to the last bit; N = 20 000 has a trailing
+    update that really saturates the GPU underneath the chain"""
+    hyp = synthetic.HYP_BATTGP if kid == K.KERNEL_BATTGP else synthetic.HYP_MATERN32
+    x, y = synthetic.make_cell_data(n, seed=n + 1)
+    xq = synthetic.make_query(x, 200)
+    out = []
+    for la in (1, 1 | 32):
+        e = ExactGPEngine(kid, hyp)
+        e.set_options(nb_outer=nb, lookahead=la)
+        e.set_panel_scheme(1)
+        lml, m, v = e.fit_predict(x, y, xq, min_var=-1.0)
+        m2, v2 = e.predict(xq[:50], min_var=-1.0)  # later prediction: walks the stored tile / panel inverses
+        diag = e.factor_diag()
+        res = e.residuals(128)
+        e.close()
+        assert res[0] < 1e-6 and res[1] < 1e-11, res
+        out.append((lml, m, v, m2, v2, diag))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert np.array_equal(a, b)
+
+
 def test_default_panel_width_is_chosen_by_size():
     """no explicit nb_outer: 512 below N = 32 768, 1024 from there on; results agree with an explicit 512"""
     n = 33000

@@ -1,0 +1,62 @@
+#!/bin/bash
+# One gpurun call that collects everything a round needs, most important first (a cut-off call loses the tail only):
+#   1 the -m gpu suite   2 the default bench line   3 rocprofv3 kernel stats of the headline config
+#   4 the PMC passes of the headline config (separate passes, tools/profile_round.sh)   5 mid-N sweep, system flow,
+#   training iteration, steady fill, single-rank proxy of the sharded driver (plain and through a one-process RCCL group)
+#       gpurun --timeout 3300 -- 'bash tools/gpu_session.sh r02 [stage ...]'
+# Everything lands under gpurun_out/<tag>s/ ; copy what is to be judged into profiles/ afterwards
+# (python tools/pmc_summary.py gpurun_out/<tag>s/pmc131k <tag> 131072 matern32).
+TAG=${1:-r02}; shift
+STAGES=${*:-"tests bench stats pmc sweep system train fill sharded"}
+REPO=$(pwd); OUT=$REPO/gpurun_out/${TAG}s; mkdir -p $OUT
+export TMPDIR=/tmp
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+stamp() { echo "[$(date +%H:%M:%S)] $*" | tee -a $OUT/session.log; }
+
+if has tests; then
+  stamp "pytest -m gpu"
+  timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest_gpu.log 2>&1
+  stamp "pytest rc=$? $(tail -1 $OUT/pytest_gpu.log)"
+fi
+if has bench; then
+  stamp "bench default"
+  timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench_default.json 2> $OUT/bench_default.err
+  stamp "bench rc=$? $(cut -c1-200 $OUT/bench_default.json)"
+fi
+if has stats; then
+  stamp "rocprofv3 kernel stats, N = 131072 matern32"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats131k -o st -- \
+     python $REPO/bench.py --steps 1 --warmup 1 --no-extras --cpu-n 0 --no-residuals > $OUT/stats131k.log 2>&1)
+  find $OUT/stats131k -name '*kernel_trace.csv' -delete   # hundreds of thousands of rows; the stats file is what is kept
+fi
+if has pmc; then
+  stamp "PMC passes, N = 131072 matern32"
+  bash tools/profile_round.sh ${TAG}s/pmc131k 131072 matern32 > $OUT/pmc131k.log 2>&1
+  stamp "PMC passes, N = 40000 battgp"
+  bash tools/profile_round.sh ${TAG}s/pmc40k 40000 battgp > $OUT/pmc40k.log 2>&1
+fi
+if has sweep; then
+  stamp "sweep over N"
+  BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 1024 2048 4096 8192 16384 32768 40000 65536 > $OUT/sweep_n.jsonl 2> $OUT/sweep_n.err
+fi
+if has system; then
+  stamp "system flow (1 pack + 8 cells)"
+  timeout 600 python tools/system_probe.py 1000 4000 16000 > $OUT/system_auto.jsonl 2> $OUT/system.err
+  BGP_STREAMS=1 timeout 600 python tools/system_probe.py 1000 4000 16000 > $OUT/system_seq.jsonl 2>> $OUT/system.err
+fi
+if has train; then
+  stamp "optimiser iteration (LML + gradient)"
+  timeout 600 python tools/train_iter.py 1000 4000 16000 40000 > $OUT/train_iter.jsonl 2> $OUT/train_iter.err
+fi
+if has fill; then
+  stamp "steady fill"
+  timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate.txt 2>&1
+fi
+if has sharded; then
+  stamp "sharded driver, single-rank proxy"
+  timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras > $OUT/sharded_n65536.json 2> $OUT/sharded.err
+  timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras --force-group > $OUT/sharded_n65536_rccl.json 2>> $OUT/sharded.err
+  timeout 900 python bench.py --mode sharded --n 131072 --kernel battgp --steps 1 --warmup 0 --cpu-n 0 --no-extras > $OUT/sharded_n131072.json 2>> $OUT/sharded.err
+fi
+stamp done
+ls -la $OUT
