@@ -7,7 +7,7 @@
 # Everything lands under gpurun_out/<tag>s/ ; copy what is to be judged into profiles/ afterwards
 # (python tools/pmc_summary.py gpurun_out/<tag>s/pmc131k <tag> 131072 matern32).
 TAG=${1:-r02}; shift
-STAGES=${*:-"tests bench stats pmc sweep system train fill sharded"}
+STAGES=${*:-"tests bench stats pmc sweep slim system train fill sharded"}
 REPO=$(pwd); OUT=$REPO/gpurun_out/${TAG}s; mkdir -p $OUT
 export TMPDIR=/tmp
 has() { [[ " $STAGES " == *" $1 "* ]]; }
@@ -38,6 +38,16 @@ fi
 if has sweep; then
   stamp "sweep over N"
   BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 1024 2048 4096 8192 16384 32768 40000 65536 > $OUT/sweep_n.jsonl 2> $OUT/sweep_n.err
+fi
+if has slim; then
+  stamp "slim chain kernels A/B (lookahead 1 vs 1|32), scheme 1"
+  for la in 1 33; do
+    BGP_LA=$la BGP_SCHEME=1 BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 8192 16384 24576 32768 40000 65536 > $OUT/sweep_la$la.jsonl 2>> $OUT/sweep_n.err
+  done
+  (cd /tmp && BGP_LA=33 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl16k_slim -o tl -- \
+     python $REPO/tools/profile_workload.py 16384 battgp 3 > $OUT/tl16k_slim.log 2>&1)
+  python tools/timeline.py $(find $OUT/tl16k_slim -name '*kernel_trace.csv' | head -1) > $OUT/tl16k_slim_summary.txt 2>&1
+  gzip -f $(find $OUT/tl16k_slim -name '*kernel_trace.csv') 2>/dev/null
 fi
 if has system; then
   stamp "system flow (1 pack + 8 cells)"

@@ -20,6 +20,8 @@ xq = synthetic.make_query(x, 300)
 tx, ty, tq = (torch.from_numpy(a).cuda() for a in (x, y, xq))
 torch.cuda.synchronize()
 eng = ExactGPEngine(kid, hyp, device=0)
+if os.environ.get("BGP_LA"):  # look-ahead word (+32: slim chain kernels)
+    eng.set_options(lookahead=int(os.environ["BGP_LA"]))
 if os.environ.get("BGP_PANEL_SCHEME"):
     eng.set_panel_scheme(int(os.environ["BGP_PANEL_SCHEME"]))
 tm = torch.empty(300, dtype=torch.float64, device="cuda")

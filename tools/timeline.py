@@ -26,9 +26,9 @@ if fills:
 def kind(name):
     if "gemm_nt_kernel<128, 128, 2" in name:
         return "deep"
-    if "gemm_nt_kernel<128, 128, 0" in name or "gemm_nt_kernel<64, 64, 0" in name:
+    if "gemm_nt_kernel<128, 128, 0" in name or "gemm_nt_kernel<64, 64, 0" in name or "chain_gemm_slim_kernel<0" in name:
         return "upd"
-    if "gemm_nt_kernel<128, 64, 1" in name or "gemm_nt_kernel<64, 64, 1" in name:
+    if "gemm_nt_kernel<128, 64, 1" in name or "gemm_nt_kernel<64, 64, 1" in name or "chain_gemm_slim_kernel<1" in name:
         return "trsm"
     if "potrf_tile" in name:
         return "tile"
