@@ -175,9 +175,10 @@ struct TrailTimer {
     BGP_HIP(h, hipEventRecord(h->ev_pool[used], st));
     return 0;
   }
-  int end(hipStream_t st, double m, double ncols, double k) {
-    // algorithmic flop of a lower (trapezoid, m rows x ncols columns) rank-k update: 2 k * #entries(i >= j)
-    flop += 2.0 * k * (ncols * (m - ncols) + ncols * (ncols + 1.0) / 2.0);
+  int end(hipStream_t st, double m, double ncols, double k, bool rect = false) {
+    // algorithmic flop of a lower (trapezoid, m rows x ncols columns) rank-k update: 2 k * #entries(i >= j);
+    // rect: a full m x ncols rectangle below the diagonal blocks
+    flop += rect ? 2.0 * k * m * ncols : 2.0 * k * (ncols * (m - ncols) + ncols * (ncols + 1.0) / 2.0);
     if (!on) return 0;
     BGP_HIP(h, hipEventRecord(h->ev_pool[used + 1], st));
     used += 2;
@@ -287,7 +288,9 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
     return bgp_fail(h, -1, "slab width %lld is not a multiple of nb_outer=%lld", (long long)V.W, (long long)NB);
   // lookahead: bits 0-2 = depth d (0 = off), bit 3 = order the panel stream's updates before rest(k),
   // bit 4 = no atomic-accumulate epilogue (ablation), bit 5 = slim chain kernels for a diagonal-block chain that
-  // runs underneath a trailing update (they fit beside its two workgroups per CU instead of queueing for a slot)
+  // runs underneath a trailing update (they fit beside its two workgroups per CU instead of queueing for a slot),
+  // bit 6 = split panels (see below): only the NEXT diagonal block's rows of the solve and of the look-ahead update
+  // stay on the panel stream's critical path
   const int depth_req = h->lookahead & 7;
   const bool la = depth_req != 0 && n > NB;  // from two panels on
   const int depth = la ? (depth_req > BGP_MAX_WBUF - 1 ? BGP_MAX_WBUF - 1 : depth_req) : 0;
@@ -318,7 +321,21 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   const int nbuf = depth + 1;  // solved-panel buffers alive at once: the sources of the next panel + the one being written
   if (dmode && (rc = ensure_panel_ws(h, nrows, NB, nbuf))) return rc;
   hipStream_t sc = h->s_copy;
-  const size_t EV_COPY = 4;  // ev_sync layout: 0 start, then per step {1 panel done, 2 rest done, 3 solve done, 4 copy done}
+  // Split panels (depth 1, scheme 1).  chain(k+1) works on the NEXT diagonal block only, and that block needs just the
+  // first nbn rows of the solved panel k and the nbn x nbn corner of the look-ahead update.  So the panel stream runs
+  //   chain(k) -> diag_out -> solve of rows [K1, K2) ("head") -> update of the corner A[K1:K2, K1:K2] -> chain(k+1)
+  // and the tall remainders - solve of the rows from K2 down ("body"), update of A[K2:, K1:K2] - go to the bulk
+  // stream sb, next to rest(k) on the main stream.  Per panel the serial path loses a solve and an update over ~N rows
+  // (what bounds the second half of the panels, where rest(k) is shorter than the chain).  Every element still
+  // receives the same operations in the same order: bit-identical to the unsplit schedule.
+  const bool split = la && dmode && depth == 1 && (h->lookahead & 64) != 0;
+  hipStream_t sb = h->s_bulk;
+  if (split) {  // sb must not start before the caller's work on st either
+    BGP_HIP(h, hipStreamWaitEvent(sb, ev, 0));
+  }
+  // ev_sync layout: 0 start, then per step {1 panel done, 2 rest done, 3 solve (body) done, 4 copy done,
+  //                                          5 head solved, 6 diag_out done, 7 body update done, 8 spare}
+  const size_t EV_COPY = 8;
   auto step_event = [&](int stp, size_t which, hipEvent_t* out) { return sync_event(h, which + EV_COPY * (size_t)stp, out); };
   struct Src {  // a factored panel as the operand of later updates
     int64_t K0, nbk, K1;
@@ -367,9 +384,38 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
       // panel 0 has no trailing update above it: nothing to fit beside
       const bool slim = la && step > 0 && (h->lookahead & 32) != 0;
       if ((rc = factor_panel(h, sp, h->dD, 2 * nbk, ldd, inv, dinfo, 0, nbk, K0, slim))) return rc;
+      // split: the bulk stream's solve of the previous panel still reads dLinv
+      if (split && step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[3 + EV_COPY * (size_t)(step - 1)], 0));
       if ((rc = launch_diag_out(h, sp, h->dD, ldd, Akk, ldk, h->dLinv, NB, (int)nbk, slim ? 1 : 0))) return rc;
       const int64_t rows_below = nrows - K1;
-      if (rows_below > 0) {
+      // split: this panel's rows below the diagonal block were last written by the bulk stream's update
+      if (split && step > 0 && rows_below > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[7 + EV_COPY * (size_t)(step - 1)], 0));
+      if (split && rows_trail > 0) {
+        const int64_t nbn = (rows_trail < NB) ? rows_trail : NB, K2 = K1 + nbn;
+        double* W = h->dW[step % nbuf];
+        hipEvent_t evD, evH, evB, evC;
+        if ((rc = step_event(step, 6, &evD)) || (rc = step_event(step, 5, &evH)) || (rc = step_event(step, 3, &evB)) ||
+            (rc = step_event(step, 4, &evC)))
+          return rc;
+        BGP_HIP(h, hipEventRecord(evD, sp));
+        if (step >= nbuf) {  // the copy-back of the panel that used this buffer
+          BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[4 + EV_COPY * (size_t)(step - nbuf)], 0));
+          BGP_HIP(h, hipStreamWaitEvent(sb, h->ev_sync[4 + EV_COPY * (size_t)(step - nbuf)], 0));
+        }
+        // head: rows [K1, K2) - all the next chain needs
+        if ((rc = launch_gemm_nt(h, sp, 1, 64, W, h->ldw, V.at(K1, K0), ldk, h->dLinv, NB, nbn, nbk, nbk, 0, dinfo, 1))) return rc;
+        BGP_HIP(h, hipEventRecord(evH, sp));
+        // body: rows from K2 down, on the bulk stream
+        BGP_HIP(h, hipStreamWaitEvent(sb, evD, 0));
+        if ((rc = launch_gemm_nt(h, sb, 1, 64, W + nbn, h->ldw, V.at(K2, K0), ldk, h->dLinv, NB, rows_below - nbn, nbk, nbk, 0, dinfo, 1)))
+          return rc;
+        BGP_HIP(h, hipEventRecord(evB, sb));
+        BGP_HIP(h, hipStreamWaitEvent(sc, evH, 0));
+        BGP_HIP(h, hipStreamWaitEvent(sc, evB, 0));
+        if ((rc = launch_copy_panel(h, sc, W, h->ldw, V.at(K1, K0), ldk, rows_below, (int)nbk))) return rc;
+        BGP_HIP(h, hipEventRecord(evC, sc));
+        Wk = W;
+      } else if (rows_below > 0) {
         double* W = h->dW[step % nbuf];
         // W[step % nbuf] was the operand of panel step - nbuf: its updates on sp are ordered before us, its
         // rest() finished before the sp updates of the previous iteration started, its copy-back is waited for
@@ -393,6 +439,35 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
     }
     const int64_t nbn = (rows_trail < NB) ? rows_trail : NB;  // width of the next panel
     const int64_t K2 = K1 + nbn;
+    if (split) {
+      const Src& p = src[step];
+      const int tmode = tmode_of(nbk);
+      hipEvent_t evH = h->ev_sync[5 + EV_COPY * (size_t)step], evB = h->ev_sync[3 + EV_COPY * (size_t)step], evLB;
+      // rest(k) on st reads the whole solved panel
+      BGP_HIP(h, hipStreamWaitEvent(st, evH, 0));
+      BGP_HIP(h, hipStreamWaitEvent(st, evB, 0));
+      // the next panel's columns were last written on st by rest(k-1)
+      if (step >= 1) {
+        BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[2 + EV_COPY * (size_t)(step - 1)], 0));
+        BGP_HIP(h, hipStreamWaitEvent(sb, h->ev_sync[2 + EV_COPY * (size_t)(step - 1)], 0));
+      }
+      // corner A[K1:K2, K1:K2] on the panel stream ...
+      if ((rc = tt.begin(sp))) return rc;
+      if ((rc = launch_gemm_nt(h, sp, tmode, 128, V.at(K1, K1), V.ld(K1), p.W, h->ldw, p.W, h->ldw, nbn, nbn, nbk, 1, dinfo))) return rc;
+      if ((rc = tt.end(sp, (double)nbn, (double)nbn, (double)nbk))) return rc;
+      // ... the rows from K2 down of the same columns on the bulk stream (its own solve is ordered before it)
+      BGP_HIP(h, hipStreamWaitEvent(sb, evH, 0));
+      const int64_t mb = (n - K2) + extra;
+      if ((rc = tt.begin(sb))) return rc;
+      if ((rc = launch_gemm_nt(h, sb, tmode, 128, V.at(K2, K1), V.ld(K1), p.W + nbn, h->ldw, p.W, h->ldw, mb, nbn, nbk, 0, dinfo))) return rc;
+      if ((rc = tt.end(sb, (double)mb, (double)nbn, (double)nbk, true))) return rc;
+      if ((rc = step_event(step, 7, &evLB))) return rc;
+      BGP_HIP(h, hipEventRecord(evLB, sb));
+      if (K2 < n && (rc = update(st, tmode, p, K2, n))) return rc;
+      if ((rc = step_event(step, 2, &ev))) return rc;
+      BGP_HIP(h, hipEventRecord(ev, st));
+      continue;
+    }
     if (!la_first) {  // panel(k) complete -> rest(k) may start on st
       if ((rc = step_event(step, 1, &ev))) return rc;
       BGP_HIP(h, hipEventRecord(ev, sp));
@@ -413,6 +488,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
     if ((rc = step_event(step, 2, &ev))) return rc;
     BGP_HIP(h, hipEventRecord(ev, st));
   }
+  if (split) BGP_HIP(h, hipStreamSynchronize(sb));
   if (dmode) BGP_HIP(h, hipStreamSynchronize(sc));
   int info = 0;
   if ((rc = check_info(h, st, la ? sp : nullptr, dinfo, &info))) return rc;
@@ -898,6 +974,7 @@ void destroy_now(bgp_handle* h) {
   if (h->s_main) (void)hipStreamDestroy(h->s_main);
   if (h->s_aux) (void)hipStreamDestroy(h->s_aux);
   if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
+  if (h->s_bulk) (void)hipStreamDestroy(h->s_bulk);
   delete h;
 }
 
@@ -997,6 +1074,7 @@ int bgp_create(bgp_handle** out, int device) {
   // slots LATER (99 us vs 12 us) than a default one next to a staggered big grid (tools/prio_probe.hip)
   CREATE_HIP(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
   CREATE_HIP(hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
+  CREATE_HIP(hipStreamCreateWithFlags(&h->s_bulk, hipStreamNonBlocking));
   CREATE_HIP(hipEventCreate(&h->ev_a));
   CREATE_HIP(hipEventCreate(&h->ev_b));
   CREATE_HIP(hipEventCreate(&h->ev_c));
@@ -1021,6 +1099,7 @@ void bgp_destroy(bgp_handle* h) {
   if (h->s_main) (void)hipStreamSynchronize(h->s_main);
   if (h->s_aux) (void)hipStreamSynchronize(h->s_aux);
   if (h->s_copy) (void)hipStreamSynchronize(h->s_copy);
+  if (h->s_bulk) (void)hipStreamSynchronize(h->s_bulk);
   {
     HandlePool& p = pool();
     std::lock_guard<std::mutex> lk(p.mu);

@@ -105,7 +105,9 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
  *                    stream's (per-launch timings do not overlap, ~1 % slower); +16: trailing updates
  *                    without the atomic-accumulate epilogue (ablation); +32: the diagonal-block chain of a panel that
  *                    is factored underneath a trailing update uses kernels sized to fit NEXT TO the update's two
- *                    workgroups per CU (<= 64 VGPRs, <= 12 KB LDS) instead of queueing for a CU slot.
+ *                    workgroups per CU (<= 64 VGPRs, <= 12 KB LDS) instead of queueing for a CU slot; +64: split
+ *                    panels - only the next diagonal block's rows of a panel's solve and look-ahead update stay on
+ *                    the panel stream, the tall rest runs on a fourth stream (depth 1, panel scheme 1).
  *                    Bit-identical results for all. */
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
 

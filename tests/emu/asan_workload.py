@@ -20,8 +20,8 @@ def main() -> int:
         from battgp_amd.engine import ExactGPEngine
 
         for kid, hyp in ((0, synthetic.HYP_BATTGP), (2, synthetic.HYP_MATERN32)):
-            cases = ((1, 1, 0, 0, 1, 0), (65, 3, 0, 1, 1, 0), (333, 70, 128, 1, 1, 0), (333, 70, 128, 0, 2, 0), (400, 9, 128, 1, 1, 256), (333, 5, 128, 1, 1 | 32, 0))
-            for n, m, nb, scheme, la, slab in cases if kid == 0 else (cases[2], cases[5]):  # cases[5]: the slim chain kernels
+            cases = ((1, 1, 0, 0, 1, 0), (65, 3, 0, 1, 1, 0), (333, 70, 128, 1, 1, 0), (333, 70, 128, 0, 2, 0), (400, 9, 128, 1, 1, 256), (333, 5, 128, 1, 1 | 32 | 64, 0))
+            for n, m, nb, scheme, la, slab in cases if kid == 0 else (cases[2], cases[5]):  # cases[5]: slim chain kernels + split panels
                 x, y = synthetic.make_cell_data(n, seed=5)
                 xq = synthetic.make_query(x, m)
                 e = ExactGPEngine(kid, hyp)

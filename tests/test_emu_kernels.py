@@ -119,7 +119,8 @@ def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
         _, g_ref = lml_and_grad(kid, hyp, x, y)
         outs = {}
         for scheme in (0, 1):
-            for la in (0, 1, 2, 9, 1 | 32):  # + 32: the slim chain kernels (scheme 1, panels after the first)
+            las = (0, 1, 2, 9) + ((1 | 32, 1 | 32 | 64) if scheme == 1 else ())  # + 32: slim chain kernels, + 64: split panels
+            for la in las:
                 e = ExactGPEngine(kid, hyp)
                 e.set_options(nb_outer=128, lookahead=la)
                 e.set_panel_scheme(scheme)
@@ -134,7 +135,7 @@ def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
                     assert res[0] < 1e-7 and res[1] < 1e-12
                 e.close()
             base = outs[(scheme, 0)]
-            for la in (1, 2, 9, 1 | 32):  # look-ahead (and the slim chain kernels) never change a bit
+            for la in las[1:]:  # look-ahead, slim chain kernels, split panels: never a bit
                 assert outs[(scheme, la)][0] == base[0]
                 assert np.array_equal(outs[(scheme, la)][1], base[1]) and np.array_equal(outs[(scheme, la)][2], base[2])
             assert abs(base[0] - ref.lml) < 1e-9 * abs(ref.lml)

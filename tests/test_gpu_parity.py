@@ -492,16 +492,18 @@ def test_panel_schemes_agree_and_match_oracle(kid, n, nb):
 
 @pytest.mark.parametrize("kid", [K.KERNEL_BATTGP, K.KERNEL_MATERN32])
 @pytest.mark.parametrize("n,nb", [(700, 128), (3001, 512), (20000, 512)])
-def test_slim_chain_kernels_are_bit_identical(kid, n, nb):
+def test_slim_chain_kernels_and_split_panels_are_bit_identical(kid, n, nb):
     """lookahead bit 5: the diagonal-block chain of every panel after the first runs on the kernels sized to fit next
-    to the trailing update's workgroups (potrf_tile_slim, chain_gemm_slim, 32-wide diag_out) - same arithmetic in the
-    same order, so factor, LML, posterior and tile inverses are identical to the last bit; N = 20 000 has a trailing
-    update that really saturates the GPU underneath the chain"""
+    to the trailing update's workgroups (potrf_tile_slim, chain_gemm_slim, 32-wide diag_out); bit 6: the panel's solve
+    and look-ahead update are split into the next diagonal block's rows (panel stream) and the tall rest (bulk stream).
+    Same arithmetic in the same order for every element, so factor, LML, posterior and tile inverses are identical to
+    the last bit - which at N = 20 000 (a trailing update that really saturates the GPU, four streams in flight) is also
+    the test of the event graph that orders the streams"""
     hyp = synthetic.HYP_BATTGP if kid == K.KERNEL_BATTGP else synthetic.HYP_MATERN32
     x, y = synthetic.make_cell_data(n, seed=n + 1)
     xq = synthetic.make_query(x, 200)
     out = []
-    for la in (1, 1 | 32):
+    for la in (1, 1 | 32, 1 | 64, 1 | 32 | 64):
         e = ExactGPEngine(kid, hyp)
         e.set_options(nb_outer=nb, lookahead=la)
         e.set_panel_scheme(1)
@@ -512,9 +514,10 @@ def test_slim_chain_kernels_are_bit_identical(kid, n, nb):
         e.close()
         assert res[0] < 1e-6 and res[1] < 1e-11, res
         out.append((lml, m, v, m2, v2, diag))
-    assert out[0][0] == out[1][0]
-    for a, b in zip(out[0][1:], out[1][1:]):
-        assert np.array_equal(a, b)
+    for o in out[1:]:
+        assert o[0] == out[0][0]
+        for a, b in zip(out[0][1:], o[1:]):
+            assert np.array_equal(a, b)
 
 
 def test_default_panel_width_is_chosen_by_size():

@@ -40,11 +40,11 @@ if has sweep; then
   BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 1024 2048 4096 8192 16384 32768 40000 65536 > $OUT/sweep_n.jsonl 2> $OUT/sweep_n.err
 fi
 if has slim; then
-  stamp "slim chain kernels A/B (lookahead 1 vs 1|32), scheme 1"
-  for la in 1 33; do
+  stamp "slim chain kernels (+32) and split panels (+64) A/B, scheme 1"
+  for la in 1 33 65 97; do
     BGP_LA=$la BGP_SCHEME=1 BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 8192 16384 24576 32768 40000 65536 > $OUT/sweep_la$la.jsonl 2>> $OUT/sweep_n.err
   done
-  (cd /tmp && BGP_LA=33 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl16k_slim -o tl -- \
+  (cd /tmp && BGP_LA=97 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl16k_slim -o tl -- \
      python $REPO/tools/profile_workload.py 16384 battgp 3 > $OUT/tl16k_slim.log 2>&1)
   python tools/timeline.py $(find $OUT/tl16k_slim -name '*kernel_trace.csv' | head -1) > $OUT/tl16k_slim_summary.txt 2>&1
   gzip -f $(find $OUT/tl16k_slim -name '*kernel_trace.csv') 2>/dev/null
