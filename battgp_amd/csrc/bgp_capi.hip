@@ -443,8 +443,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
       const Src& p = src[step];
       const int tmode = tmode_of(nbk);
       hipEvent_t evH = h->ev_sync[5 + EV_COPY * (size_t)step], evB = h->ev_sync[3 + EV_COPY * (size_t)step], evLB;
-      // rest(k) on st reads the whole solved panel
-      BGP_HIP(h, hipStreamWaitEvent(st, evH, 0));
+      // rest(k) on st only reads the body rows of the solved panel (its columns start at K2)
       BGP_HIP(h, hipStreamWaitEvent(st, evB, 0));
       // the next panel's columns were last written on st by rest(k-1)
       if (step >= 1) {

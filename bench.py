@@ -363,7 +363,25 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
             extras.append(rec)
             w.close()
         out["extra_configs"] = extras
+        out["experiments"] = schedule_experiments()
     return out
+
+
+def schedule_experiments(limit_s: float = 150.0):
+    """A/B of the optional Cholesky schedules (tools/ab_lookahead.py) in a CHILD process with a time limit: they are
+    off by default until measured, and nothing they do can reach the record above."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "ab_lookahead.py"), "3", "16384", "40000"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+        lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return {"what": "fit+predict ms by lookahead word (1 default, +32 slim chain kernels, +64 split panels), panel scheme 1",
+                "rc": r.returncode, "runs": lines, "stderr_tail": r.stderr[-300:] if r.returncode else ""}
+    except subprocess.TimeoutExpired:
+        return {"rc": "timeout", "runs": []}
+    except Exception as exc:  # noqa: BLE001 - a side measurement never fails the bench
+        return {"rc": f"{type(exc).__name__}: {exc}", "runs": []}
 
 
 def run_sharded(args, rank, world, local_rank, n):

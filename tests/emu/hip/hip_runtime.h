@@ -4,8 +4,11 @@
 // be compiled for the build container's CPU ("the CPU build": logic tests of the kernels' indexing and
 // algebra while no GPU is at hand, and a target for sanitizers, which the GPU pool does not offer).  Threads
 // of a workgroup run as cooperative fibers; __syncthreads and the cross-lane operations (readlane, shuffles,
-// v_mfma_f64_16x16x4) are rendezvous points with the documented gfx950 lane layouts.  Streams are executed
-// in order and synchronously.  It says nothing about speed, memory-model races or occupancy.
+// v_mfma_f64_16x16x4) are rendezvous points with the documented gfx950 lane layouts.  By default every stream
+// operation runs at once, in host order.  With HIPEMU_SCHED = lazy | eager | random[:seed] the streams are real
+// queues: work is deferred and executed in an order that honours ONLY what the stream / event graph orders (in-stream
+// order, hipStreamWaitEvent edges, the host synchronisation calls) and is otherwise adversarial - a missing edge
+// between two streams shows up as a wrong (not bit-identical) result.  It says nothing about speed or occupancy.
 //
 // The product (battgp_amd/_lib.py) never loads the library built from this header: it is linked only into
 // tests/emu/_build/libbattgp_emu.so, which tests/test_emu_kernels.py injects into the binding by hand.
@@ -18,6 +21,8 @@
 #include <chrono>
 #include <cmath>
 #include <functional>
+#include <memory>
+#include <vector>
 
 #define HIPEMU 1
 #define __global__
@@ -48,10 +53,13 @@ enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory 
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 struct ihipStream_t {
   int id;
+  void* queue;  // hipemu's queue of this stream (deferred modes)
 };
 typedef ihipStream_t* hipStream_t;
 struct ihipEvent_t {
   double t_ms;
+  void* rec_queue;   // the queue and position of the last hipEventRecord (deferred modes)
+  uint64_t rec_seq;
 };
 typedef ihipEvent_t* hipEvent_t;
 #define hipStreamNonBlocking 1
@@ -61,6 +69,18 @@ typedef ihipEvent_t* hipEvent_t;
 namespace hipemu {
 double now_ms();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+// stream model (hipemu.cpp): immediate execution, or queues drained by an adversarial scheduler (HIPEMU_SCHED)
+void stream_create(hipStream_t s);
+void stream_destroy(hipStream_t s);
+void enqueue(hipStream_t s, std::function<void()> fn);
+void event_record(hipEvent_t e, hipStream_t s);
+void event_forget(hipEvent_t e);
+void stream_wait_event(hipStream_t s, hipEvent_t e);
+void stream_sync(hipStream_t s);
+void event_sync(hipEvent_t e);
+bool event_done(hipEvent_t e);
+void device_sync();
+bool deferred();
 struct Ctx {
   dim3 tid, bid, bdim, gdim;
 };
@@ -83,6 +103,7 @@ static inline const char* hipGetErrorString(hipError_t e) {
     case hipSuccess: return "hipSuccess";
     case hipErrorInvalidValue: return "hipErrorInvalidValue";
     case hipErrorOutOfMemory: return "hipErrorOutOfMemory";
+    case hipErrorNotReady: return "hipErrorNotReady";
     default: return "hipError";
   }
 }
@@ -92,7 +113,10 @@ static inline hipError_t hipGetDeviceCount(int* n) {
   return hipSuccess;
 }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() {
+  ::hipemu::device_sync();
+  return hipSuccess;
+}
 static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
   *free_b = (size_t)48 << 30;
   *total_b = (size_t)64 << 30;
@@ -110,6 +134,7 @@ static inline hipError_t hipMalloc(void** p, size_t bytes) {
   return hipSuccess;
 }
 static inline hipError_t hipFree(void* p) {
+  ::hipemu::device_sync();  // like the real call: nothing in flight may still use the memory
   free(p);
   return hipSuccess;
 }
@@ -119,54 +144,80 @@ static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKi
   memmove(d, s, n);
   return hipSuccess;
 }
-static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
-  memmove(d, s, n);
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind kind, hipStream_t st = nullptr) {
+  if (!::hipemu::deferred() || st == nullptr) {
+    memmove(d, s, n);
+  } else if (kind == hipMemcpyHostToDevice) {
+    // pageable host memory is staged before the call returns: the source may change or go away afterwards
+    auto staged = std::make_shared<std::vector<char>>(static_cast<const char*>(s), static_cast<const char*>(s) + n);
+    ::hipemu::enqueue(st, [d, staged]() { memcpy(d, staged->data(), staged->size()); });
+  } else {
+    ::hipemu::enqueue(st, [d, s, n]() { memmove(d, s, n); });
+  }
   return hipSuccess;
 }
 static inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind,
-                                          hipStream_t = nullptr) {
-  for (size_t r = 0; r < height; ++r) memmove(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+                                          hipStream_t st = nullptr) {
+  ::hipemu::enqueue(st, [=]() {
+    for (size_t r = 0; r < height; ++r) memmove(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+  });
   return hipSuccess;
 }
 static inline hipError_t hipMemset(void* d, int v, size_t n) {
   memset(d, v, n);
   return hipSuccess;
 }
-static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) {
-  memset(d, v, n);
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr) {
+  ::hipemu::enqueue(st, [d, v, n]() { memset(d, v, n); });
   return hipSuccess;
 }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
-  *s = new ihipStream_t{0};
+  *s = new ihipStream_t{0, nullptr};
+  ::hipemu::stream_create(*s);
   return hipSuccess;
 }
 static inline hipError_t hipStreamDestroy(hipStream_t s) {
+  ::hipemu::stream_destroy(s);
   delete s;
   return hipSuccess;
 }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) {
+  ::hipemu::stream_sync(s);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+  ::hipemu::stream_wait_event(s, e);
+  return hipSuccess;
+}
 static inline hipError_t hipEventCreate(hipEvent_t* e) {
-  *e = new ihipEvent_t{0.0};
+  *e = new ihipEvent_t{0.0, nullptr, 0};
   return hipSuccess;
 }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) {
+  ::hipemu::event_forget(e);
   delete e;
   return hipSuccess;
 }
-static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
-  e->t_ms = ::hipemu::now_ms();
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr) {
+  ::hipemu::event_record(e, s);
   return hipSuccess;
 }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t e) {
+  ::hipemu::event_sync(e);
+  return hipSuccess;
+}
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  if (!::hipemu::event_done(a) || !::hipemu::event_done(b)) return hipErrorNotReady;  // like the real call
   *ms = (float)(b->t_ms - a->t_ms);
   return hipSuccess;
 }
 
-#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-  ::hipemu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                                        \
+  do {                                                                                                   \
+    const dim3 hipemu_g_ = dim3(grid), hipemu_b_ = dim3(block);                                          \
+    ::hipemu::enqueue((stream), [=]() { ::hipemu::launch(hipemu_g_, hipemu_b_, [=]() { kern(__VA_ARGS__); }); }); \
+  } while (0)
 
 // ---- device intrinsics --------------------------------------------------------------------------------------
 #define __syncthreads() ::hipemu::block_barrier()

@@ -12,6 +12,9 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <deque>
+#include <mutex>
+#include <random>
 #include <thread>
 #include <vector>
 
@@ -240,18 +243,29 @@ void run_block(Block* b, dim3 grid, dim3 block, dim3 bid, const std::function<vo
   g_ctx = nullptr;
 }
 
+// one block context (fiber stacks) per OS thread, released when the thread ends: a launch runs its blocks on
+// short-lived worker threads, and thousands of launches must not accumulate their stacks
+struct BlockHolder {
+  Block* b = nullptr;
+  ~BlockHolder() {
+    if (b) {
+      if (b->stacks) munmap(b->stacks, STACK * MAXT);
+      delete b;
+    }
+  }
+};
 Block* worker_block() {
-  static thread_local Block* b = nullptr;
-  if (!b) {
-    b = new Block();
+  static thread_local BlockHolder h;
+  if (!h.b) {
+    h.b = new Block();
     void* m = mmap(nullptr, STACK * MAXT, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (m == MAP_FAILED) {
       perror("hipemu: mmap of fiber stacks");
       abort();
     }
-    b->stacks = static_cast<char*>(m);
+    h.b->stacks = static_cast<char*>(m);
   }
-  return b;
+  return h.b;
 }
 
 int worker_count() {
@@ -370,4 +384,250 @@ int block_or(int pred) {
   return b->orv[buf];
 }
 
+// ---- streams --------------------------------------------------------------------------------------------------
+// HIPEMU_SCHED unset / "sync": every operation runs at once (host order).  Otherwise the streams are queues:
+//   lazy          a synchronisation call runs the named stream (and whatever its event waits force), nothing else
+//   eager         ... after first draining every OTHER stream as far as it can go
+//   random[:seed] ... by running runnable queue heads in random order until the call is satisfied
+//   prio:<p>      ... by always running the runnable head of the highest-priority stream; a stream's role is its
+//                 creation index mod 4 (a handle creates main, panel, copy, bulk in that order) and <p> = 0..23
+//                 picks the permutation of the four roles: each role gets its turn to run as far ahead as it can
+// An operation therefore runs as LATE (lazy), or in as unexpected an order (eager, random), as the stream / event
+// graph allows: two launches that are ordered only by luck on the GPU come out in the wrong order here.
+namespace {
+struct StreamQ;
+struct Item {
+  int kind;  // 0 run, 1 record, 2 wait
+  std::function<void()> fn;
+  hipEvent_t ev;
+  StreamQ* dep;
+  uint64_t dep_seq;
+};
+struct StreamQ {
+  std::deque<Item> q;
+  uint64_t done = 0, enq = 0;
+  int role = 0;  // creation index mod 4
+};
+struct Sched {
+  int mode = 0;  // 0 sync, 1 lazy, 2 eager, 3 random, 4 prio
+  int rank[4] = {0, 1, 2, 3};  // prio: rank of a role (0 = runs first)
+  size_t created = 0;
+  std::mt19937_64 rng{12345};
+  std::recursive_mutex mu;
+  std::vector<StreamQ*> streams;
+  Sched() { set(getenv("HIPEMU_SCHED")); }
+  void set(const char* e) {
+    mode = 0;
+    if (!e || !*e || !strcmp(e, "sync")) return;
+    if (!strcmp(e, "lazy")) mode = 1;
+    else if (!strcmp(e, "eager")) mode = 2;
+    else if (!strncmp(e, "random", 6)) {
+      mode = 3;
+      rng.seed(e[6] == ':' ? (uint64_t)atoll(e + 7) : 12345);
+    } else if (!strncmp(e, "prio:", 5)) {
+      mode = 4;
+      int p = atoi(e + 5) % 24, roles[4] = {0, 1, 2, 3};
+      for (int i = 0; i < 4; ++i) {  // p-th permutation (factorial number system): position i holds role pick
+        int f = 1;
+        for (int k = 2; k <= 3 - i; ++k) f *= k;
+        const int idx = p / f;
+        p %= f;
+        rank[roles[idx]] = i;
+        for (int k = idx; k < 3 - i; ++k) roles[k] = roles[k + 1];
+      }
+    } else {
+      fprintf(stderr, "hipemu: unknown HIPEMU_SCHED=%s\n", e);
+      abort();
+    }
+  }
+  // mutation testing of the event graph: the drop-th hipStreamWaitEvent (counted from the last reset) is ignored
+  long wait_count = 0, wait_drop = -1;
+};
+Sched& sched() {
+  static Sched s;
+  return s;
+}
+inline StreamQ* qof(hipStream_t s) { return s ? static_cast<StreamQ*>(s->queue) : nullptr; }
+
+bool head_runnable(StreamQ* s) {
+  if (s->q.empty()) return false;
+  const Item& it = s->q.front();
+  return it.kind != 2 || it.dep->done >= it.dep_seq;
+}
+void run_head(StreamQ* s) {
+  Item it = std::move(s->q.front());
+  s->q.pop_front();
+  if (it.kind == 0) it.fn();
+  else if (it.kind == 1 && it.ev) it.ev->t_ms = now_ms();
+  ++s->done;
+}
+void advance(StreamQ* s, uint64_t upto, int depth = 0) {
+  if (depth > 64) {
+    fprintf(stderr, "hipemu: cyclic event wait between streams\n");
+    abort();
+  }
+  while (s->done < upto) {
+    const Item& it = s->q.front();
+    if (it.kind == 2 && it.dep->done < it.dep_seq) advance(it.dep, it.dep_seq, depth + 1);
+    run_head(s);
+  }
+}
+// make `s` reach position `upto` under the configured policy
+void reach(StreamQ* s, uint64_t upto) {
+  Sched& S = sched();
+  if (S.mode == 2) {
+    for (StreamQ* t : S.streams)
+      if (t != s) {
+        // as far as t can go without forcing s past what it needs anyway: run until its head waits on something
+        // that is not done, resolving waits on streams other than s
+        while (!t->q.empty()) {
+          const Item& it = t->q.front();
+          if (it.kind == 2 && it.dep->done < it.dep_seq) {
+            if (it.dep == s) break;
+            advance(it.dep, it.dep_seq);
+          }
+          run_head(t);
+        }
+      }
+    advance(s, upto);
+  } else if (S.mode == 3) {
+    while (s->done < upto) {
+      std::vector<StreamQ*> ready;
+      for (StreamQ* t : S.streams)
+        if (head_runnable(t)) ready.push_back(t);
+      if (ready.empty()) {
+        fprintf(stderr, "hipemu: no runnable stream but a synchronisation is pending (cyclic waits?)\n");
+        abort();
+      }
+      run_head(ready[S.rng() % ready.size()]);
+    }
+  } else if (S.mode == 4) {
+    while (s->done < upto) {
+      StreamQ* best = nullptr;
+      for (StreamQ* t : S.streams)
+        if (head_runnable(t) && (!best || S.rank[t->role] < S.rank[best->role])) best = t;
+      if (!best) {
+        fprintf(stderr, "hipemu: no runnable stream but a synchronisation is pending (cyclic waits?)\n");
+        abort();
+      }
+      run_head(best);
+    }
+  } else {
+    advance(s, upto);
+  }
+}
+}  // namespace
+
+bool deferred() { return sched().mode != 0; }
+
+void stream_create(hipStream_t s) {
+  Sched& S = sched();
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  StreamQ* q = new StreamQ();
+  q->role = (int)(S.created++ % 4);
+  s->queue = q;
+  S.streams.push_back(q);
+}
+void stream_destroy(hipStream_t s) {
+  Sched& S = sched();
+  if (!s) return;
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  StreamQ* q = qof(s);
+  reach(q, q->enq);
+  // other queues may still hold waits on positions of this one: they are all done, keep the (empty) queue alive
+  s->queue = nullptr;
+}
+void enqueue(hipStream_t s, std::function<void()> fn) {
+  Sched& S = sched();
+  if (!S.mode || !s) {  // immediate mode, or the null stream (which the non-blocking streams do not synchronise with)
+    fn();
+    return;
+  }
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  StreamQ* q = qof(s);
+  q->q.push_back(Item{0, std::move(fn), nullptr, nullptr, 0});
+  ++q->enq;
+}
+void event_record(hipEvent_t e, hipStream_t s) {
+  Sched& S = sched();
+  if (!S.mode || !s) {
+    e->t_ms = now_ms();
+    e->rec_queue = nullptr;
+    return;
+  }
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  StreamQ* q = qof(s);
+  // an earlier record of the same event that is still queued must not write through a stale pointer later: it stays
+  // valid (the event object lives until hipEventDestroy, which flushes)
+  q->q.push_back(Item{1, nullptr, e, nullptr, 0});
+  e->rec_queue = q;
+  e->rec_seq = ++q->enq;
+}
+void event_forget(hipEvent_t e) {
+  Sched& S = sched();
+  if (!S.mode || !e->rec_queue) return;
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  // every queued record of this event holds its pointer: flush all queues up to their current end
+  for (StreamQ* t : S.streams)
+    for (const Item& it : t->q)
+      if (it.kind == 1 && it.ev == e) {
+        reach(t, t->enq);
+        break;
+      }
+}
+void stream_wait_event(hipStream_t s, hipEvent_t e) {
+  Sched& S = sched();
+  if (!S.mode || !s || !e->rec_queue) return;  // never recorded (or recorded in immediate mode): nothing to wait for
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  StreamQ* q = qof(s);
+  StreamQ* dep = static_cast<StreamQ*>(e->rec_queue);
+  if (S.wait_count++ == S.wait_drop) return;  // mutation under test
+  // the wait captures the record that is current NOW (a later re-record of the event does not move it)
+  q->q.push_back(Item{2, nullptr, nullptr, dep, e->rec_seq});
+  ++q->enq;
+}
+void stream_sync(hipStream_t s) {
+  Sched& S = sched();
+  if (!S.mode || !s) return;
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  StreamQ* q = qof(s);
+  if (q) reach(q, q->enq);
+}
+void event_sync(hipEvent_t e) {
+  Sched& S = sched();
+  if (!S.mode || !e->rec_queue) return;
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  reach(static_cast<StreamQ*>(e->rec_queue), e->rec_seq);
+}
+bool event_done(hipEvent_t e) {
+  Sched& S = sched();
+  if (!S.mode || !e->rec_queue) return true;
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  return static_cast<StreamQ*>(e->rec_queue)->done >= e->rec_seq;
+}
+void device_sync() {
+  Sched& S = sched();
+  if (!S.mode) return;
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  // (reverse creation order: one more chance for an unordered pair to come out the wrong way round)
+  for (size_t i = S.streams.size(); i-- > 0;) reach(S.streams[i], S.streams[i]->enq);
+}
+
 }  // namespace hipemu
+
+// control surface for the tests (ctypes): switch the policy between runs, drop one wait, count them
+extern "C" {
+void hipemu_set_sched(const char* policy) {
+  hipemu::device_sync();
+  std::lock_guard<std::recursive_mutex> lk(hipemu::sched().mu);
+  hipemu::sched().set(policy);
+}
+void hipemu_drop_wait(long k) {
+  std::lock_guard<std::recursive_mutex> lk(hipemu::sched().mu);
+  hipemu::sched().wait_count = 0;
+  hipemu::sched().wait_drop = k;
+}
+long hipemu_wait_count(void) { return hipemu::sched().wait_count; }
+// a host-side stand-in for "work that torch enqueues on this stream" runs behind everything the stream already holds
+void hipemu_stream_sync(void* stream) { hipemu::stream_sync(static_cast<hipStream_t>(stream)); }
+}

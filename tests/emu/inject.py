@@ -22,6 +22,7 @@ def load_emu(sanitize: bool = False) -> C.CDLL:
     key = str(sanitize) if sanitize else "plain"
     if key not in _cache:
         lib = C.CDLL(build_emu.build(sanitize=sanitize))
+        lib.hipemu_stream_sync.argtypes = [C.c_void_p]
         for name, (res, args) in _lib.SIGNATURES.items():
             fn = getattr(lib, name)  # the CPU build must export the whole C-ABI too
             fn.restype = res
@@ -95,13 +96,23 @@ def fake_cuda_tensors():
     torch.cuda.current_device = lambda: 0
     torch.cuda.empty_cache = lambda: None
     torch.cuda.mem_get_info = lambda *a, **k: (48 << 30, 64 << 30)
-    torch.cuda.stream = lambda s: contextlib.nullcontext()
+
+    # torch work "on the engine's stream" (sharded.py makes the engine's stream current around its buffer operations
+    # and collectives) is host work here: it runs behind everything the stream already holds
+    @contextlib.contextmanager
+    def on_stream(s):
+        ptr = getattr(s, "ptr", None)
+        if ptr and "plain" in _cache:
+            _cache["plain"].hipemu_stream_sync(ptr)
+        yield
+
+    torch.cuda.stream = on_stream
     torch.cuda.is_current_stream_capturing = lambda: False  # torch.optim's capture health check
     torch.Tensor.is_cuda = property(lambda self: True)      # "device" tensors live on the host here
 
     class _Stream:
-        def __init__(self, *a, **k):
-            pass
+        def __init__(self, ptr=None, *a, **k):
+            self.ptr = ptr
 
         def synchronize(self):
             pass

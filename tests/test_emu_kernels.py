@@ -182,3 +182,26 @@ def test_address_sanitizer_pass():
     r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "asan_workload.py")], env=env, capture_output=True, text=True, timeout=900)
     assert "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0 and "ASAN-PASS-DONE" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_stream_graph_under_adversarial_schedules(emu):
+    """The CPU build's streams as real queues (tests/emu/hipemu.cpp): every launch deferred and run in an order that
+    honours only in-stream order, event waits and host synchronisation - lazily, eagerly, randomly, and with each of the
+    four stream roles (main, panel, copy, bulk) in turn running as far ahead as the graph allows.  All schedules of the
+    blocked Cholesky (no look-ahead, depth 1 / 2, ordered, slim chain kernels, split panels) followed by a later
+    prediction and the gradient must reproduce the immediate-mode result bit for bit: a missing hipStreamWaitEvent edge
+    would not (tests/emu/stream_graph_check.py --mutate drops every wait in turn to show that it is noticed)."""
+    import ctypes as C
+
+    import stream_graph_check as G
+
+    emu.hipemu_set_sched.argtypes = [C.c_char_p]
+    emu.hipemu_set_sched(b"sync")
+    try:
+        ref = G.workload(1)
+        las = (0, 1, 2, 1 | 8, 1 | 32 | 64)
+        assert all(G.same(G.workload(la), ref) for la in las)
+        for policy in ("lazy", "eager", "random:3", "prio:1", "prio:6", "prio:10", "prio:15", "prio:20", "prio:23"):
+            assert G.run_policy(emu, policy, las, ref) == [], policy
+    finally:
+        emu.hipemu_set_sched(b"sync")
