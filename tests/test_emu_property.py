@@ -1,0 +1,35 @@
+"""Property test of the whole C-ABI path on the CPU build of the kernel sources (tests/emu): random sizes (ragged: N, M
+not multiples of anything), input dimensions 1..6, all four kernels, random hyper-parameters over decades, unsorted /
+duplicated time stamps, coincident points, both panel schemes, every look-ahead word, the column-slab layout - LML,
+posterior mean and variance against the oracle, and (where the engine offers one) the analytic gradient against the
+oracle's.  Derandomised (the same examples every run).  The same property runs on the GPU as
+tests/test_gpu_parity.py::test_random_problems_match_the_oracle with sizes a GPU likes."""
+
+import os
+import sys
+
+import pytest
+from hypothesis import HealthCheck, given, settings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emu"))
+sys.path.insert(0, HERE)
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from inject import installed
+
+    with installed() as lib:
+        yield lib
+
+
+from problem_gen import check_problem, problems  # noqa: E402
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(problems())
+def test_random_problems_match_the_oracle_on_the_cpu_build(emu, prob):
+    check_problem(*prob)

@@ -4,10 +4,15 @@ compares with the CPU oracle / committed golden vectors.  Tolerances are the nor
 
 import json
 import os
+import sys
 import warnings
 
 import numpy as np
 import pytest
+from hypothesis import HealthCheck, given, settings
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from problem_gen import check_problem, problems  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -518,6 +523,15 @@ def test_slim_chain_kernels_and_split_panels_are_bit_identical(kid, n, nb):
         assert o[0] == out[0][0]
         for a, b in zip(out[0][1:], o[1:]):
             assert np.array_equal(a, b)
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(problems(n_max=3000, m_max=400, noise_lo=-3.0))
+def test_random_problems_match_the_oracle(prob):
+    """the property of tests/test_emu_property.py at sizes with dozens of panels: ragged N / M, D = 1..6, all kernels,
+    random hyper-parameters, duplicated points, both panel schemes, every look-ahead word, slab layout - LML, posterior
+    and gradient against the oracle"""
+    check_problem(*prob)
 
 
 def test_default_panel_width_is_chosen_by_size():
