@@ -135,13 +135,17 @@ struct PhaseTimer {
 // `A` is the origin of the panel's slab (or of a stand-alone panel), K0 the panel's first column
 // relative to it and `gofs` the global index of that origin (tile inverses and the failing-minor
 // report are indexed globally).
-// `slim`: the chain kernels that fit next to two resident trailing-update workgroups (bgp_linalg.hip); same results
+// `slim`: the chain kernels that fit next to two resident trailing-update workgroups (bgp_linalg.hip);
+// `fuse`: the rank-64 update of step j and the tile Cholesky of step j + 1 in one launch (two dependent launches per
+// 64 columns instead of three; while the update is at most ~1500 tiles).  Same results either way.
 int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t nrows, int64_t lda, double* inv, int* dinfo,
-                 int64_t K0, int64_t nbk, int64_t gofs = 0, bool slim = false) {
+                 int64_t K0, int64_t nbk, int64_t gofs = 0, bool slim = false, bool fuse = false) {
+  bool tile_done = false;  // the diagonal tile of this step was factored by the previous step's fused launch
   for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
     double* inv_j = inv + ((j + gofs) / BGP_IB) * (BGP_IB * BGP_IB);
-    int rc = launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)(j + gofs), slim ? 1 : 0);
+    int rc = tile_done ? 0 : launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)(j + gofs), slim ? 1 : 0);
     if (rc) return rc;
+    tile_done = false;
     const int64_t rows_below = nrows - (j + BGP_IB);
     if (rows_below > 0) {
       double* A21 = A + (j + BGP_IB) + j * lda;
@@ -151,8 +155,14 @@ int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t nrows, int64_
       const int64_t ncols = K0 + nbk - (j + BGP_IB);
       if (ncols > 0) {
         double* A22 = A + (j + BGP_IB) + (j + BGP_IB) * lda;
-        rc = slim ? launch_chain_gemm_slim(h, st, 0, A22, lda, A21, lda, A21, lda, rows_below, ncols, 1, dinfo)
-                  : launch_gemm_nt(h, st, 0, 128, A22, lda, A21, lda, A21, lda, rows_below, ncols, BGP_IB, 1, dinfo);
+        if (fuse && !slim && ((rows_below + 63) / 64) * (ncols / 64) <= 1536) {
+          rc = launch_chain_update_potrf(h, st, A22, lda, A21, lda, A21, lda, rows_below, ncols, 1, dinfo, inv_j + BGP_IB * BGP_IB,
+                                         (int)(j + BGP_IB + gofs));
+          tile_done = true;
+        } else {
+          rc = slim ? launch_chain_gemm_slim(h, st, 0, A22, lda, A21, lda, A21, lda, rows_below, ncols, 1, dinfo)
+                    : launch_gemm_nt(h, st, 0, 128, A22, lda, A21, lda, A21, lda, rows_below, ncols, BGP_IB, 1, dinfo);
+        }
         if (rc) return rc;
       }
     }
@@ -290,7 +300,8 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   // bit 4 = no atomic-accumulate epilogue (ablation), bit 5 = slim chain kernels for a diagonal-block chain that
   // runs underneath a trailing update (they fit beside its two workgroups per CU instead of queueing for a slot),
   // bit 6 = split panels (see below): only the NEXT diagonal block's rows of the solve and of the look-ahead update
-  // stay on the panel stream's critical path
+  // stay on the panel stream's critical path, bit 7 = rank-64 update of a chain step + tile Cholesky of the next step
+  // in one launch (factor_panel)
   const int depth_req = h->lookahead & 7;
   const bool la = depth_req != 0 && n > NB;  // from two panels on
   const int depth = la ? (depth_req > BGP_MAX_WBUF - 1 ? BGP_MAX_WBUF - 1 : depth_req) : 0;
@@ -329,6 +340,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   // (what bounds the second half of the panels, where rest(k) is shorter than the chain).  Every element still
   // receives the same operations in the same order: bit-identical to the unsplit schedule.
   const bool split = la && dmode && depth == 1 && (h->lookahead & 64) != 0;
+  const bool fuse = (h->lookahead & 128) != 0;
   hipStream_t sb = h->s_bulk;
   if (split) {  // sb must not start before the caller's work on st either
     BGP_HIP(h, hipStreamWaitEvent(sb, ev, 0));
@@ -376,14 +388,14 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
     const int64_t s0 = V.slab(K0) * V.W;  // origin of the panel's slab
     const double* Wk = nullptr;
     if (!dmode) {
-      if ((rc = factor_panel(h, sp, V.at(s0, s0), nrows - s0, V.ld(K0), inv, dinfo, K0 - s0, nbk, s0))) return rc;
+      if ((rc = factor_panel(h, sp, V.at(s0, s0), nrows - s0, V.ld(K0), inv, dinfo, K0 - s0, nbk, s0, false, fuse))) return rc;
     } else {
       const int64_t ldk = V.ld(K0), ldd = 2 * NB;
       double* Akk = V.at(K0, K0);
       if ((rc = launch_diag_in(h, sp, Akk, ldk, h->dD, ldd, (int)nbk))) return rc;
       // panel 0 has no trailing update above it: nothing to fit beside
       const bool slim = la && step > 0 && (h->lookahead & 32) != 0;
-      if ((rc = factor_panel(h, sp, h->dD, 2 * nbk, ldd, inv, dinfo, 0, nbk, K0, slim))) return rc;
+      if ((rc = factor_panel(h, sp, h->dD, 2 * nbk, ldd, inv, dinfo, 0, nbk, K0, slim, fuse))) return rc;
       // split: the bulk stream's solve of the previous panel still reads dLinv
       if (split && step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[3 + EV_COPY * (size_t)(step - 1)], 0));
       if ((rc = launch_diag_out(h, sp, h->dD, ldd, Akk, ldk, h->dLinv, NB, (int)nbk, slim ? 1 : 0))) return rc;

@@ -202,7 +202,9 @@ __host__ int64_t lower_blocks(int nti, int ntj) {
 // time column is ascending, so min(t_i, t_j) = t_j and the integrated-Wiener term
 //   s_w (min^3/3 + |t_i - t_j| min^2/2) = (s_w t_j^2 / 2) t_i - s_w t_j^3 / 6 = A_j t_i + B_j
 // is ONE fma with two per-column constants staged next to the column point (w[0] = A_j, w[1] = B_j).
-template <int KID, int DD, bool SORTED>
+// T256: the 256-entry table / degree-4 exponential (exp_interior, one FMA less per entry; NOT yet timed on the GPU -
+// the default is the 64-entry / degree-5 form whose rates are on record)
+template <int KID, int DD, bool SORTED, bool T256 = false>
 __device__ __forceinline__ double kfun_interior(const double (&a)[DD], const double (&b)[DD], const double (&w)[2], int D,
                                                 double s0, const double* __restrict__ tbl) {
   if (KID == BGP_KERNEL_BATTGP) {
@@ -213,7 +215,7 @@ __device__ __forceinline__ double kfun_interior(const double (&a)[DD], const dou
         const double df = a[d] - b[d];
         q = __builtin_fma(df, df, q);
       }
-    const double e = exp_interior(-q, tbl);  // s_r e^-q
+    const double e = T256 ? exp_interior(-q, tbl) : exp_nonpos_t<true>(-q, tbl);  // s_r e^-q
     if (SORTED) return __builtin_fma(w[0], a[0], w[1]) + e;
     const double m = __builtin_fmin(a[0], b[0]);
     const double mx = __builtin_fmax(a[0], b[0]);
@@ -231,7 +233,7 @@ __device__ __forceinline__ double kfun_interior(const double (&a)[DD], const dou
     const double y = __builtin_amdgcn_rsq(q);
     double r = q * y;
     r = __builtin_fma(__builtin_fma(-r, r, q), 0.5 * y, r);
-    const double se = exp_interior(-r, tbl);  // s e^-r
+    const double se = T256 ? exp_interior(-r, tbl) : exp_nonpos_t<true>(-r, tbl);  // s e^-r
     return __builtin_fma(r, se, se);
   } else {
     double q = 0.0;
@@ -241,7 +243,7 @@ __device__ __forceinline__ double kfun_interior(const double (&a)[DD], const dou
         const double df = a[d] - b[d];
         q = __builtin_fma(df, df, q);
       }
-    return exp_interior(-q, tbl);
+    return T256 ? exp_interior(-q, tbl) : exp_nonpos_t<true>(-q, tbl);
   }
 }
 
@@ -264,14 +266,18 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
   const int D = DT ? DT : p.D;
   __shared__ double sB[FT_COLS][DD];
   __shared__ double sW[FT_COLS][2];  // K0: A_j = s_w t_j^2 / 2, B_j = -s_w t_j^3 / 6
-  __shared__ double sT[64];          // 2^(i/64): the general path's table ...
-  __shared__ double sTs[256];        // ... and 2^(i/256) times the output scale (s_r for K0, s otherwise): interior tiles
-  {
-    const double oscale = (KID == BGP_KERNEL_BATTGP) ? p.s1 : p.s0;
+  constexpr bool T256 = (ABL & 4) != 0;  // ABL bit 2: the 256-entry interior table (BGP_FILL_TABLE=256, not yet timed)
+  __shared__ double sT[64];          // 2^(i/64) ...
+  __shared__ double sTs[T256 ? 256 : 64];  // ... and the same (or 2^(i/256)) times the output scale (s_r for K0, s otherwise)
+  const double oscale = (KID == BGP_KERNEL_BATTGP) ? p.s1 : p.s0;
+  if (T256) {
     // 2^(1/256), 2^(2/256), 2^(3/256) correctly rounded; 2^(i/256) = 2^((i >> 2)/64) 2^((i & 3)/256) to ~1 ulp
     const double fine[4] = {1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175};
     if (threadIdx.x < 64) sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
-    sTs[threadIdx.x] = (EXP2_TBL[threadIdx.x >> 2] * fine[threadIdx.x & 3]) * oscale;
+    sTs[threadIdx.x % (T256 ? 256 : 64)] = (EXP2_TBL[threadIdx.x >> 2] * fine[threadIdx.x & 3]) * oscale;
+  } else if (threadIdx.x < 64) {
+    sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
+    sTs[threadIdx.x] = EXP2_TBL[threadIdx.x] * oscale;
   }
 
   int ti, tj;
@@ -330,8 +336,8 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
           w[0] = sW[c][0];
           w[1] = sW[c][1];
         }
-        double v0 = (ABL & 1) ? a0[1] + b[1] : kfun_interior<KID, DD, SORTED>(a0, b, w, D, s0, sTs);
-        double v1 = (ABL & 1) ? a1[1] - b[1] : kfun_interior<KID, DD, SORTED>(a1, b, w, D, s0, sTs);
+        double v0 = (ABL & 1) ? a0[1] + b[1] : kfun_interior<KID, DD, SORTED, T256>(a0, b, w, D, s0, sTs);
+        double v1 = (ABL & 1) ? a1[1] - b[1] : kfun_interior<KID, DD, SORTED, T256>(a1, b, w, D, s0, sTs);
         if (ABL & 2) {
           if (v0 + v1 == 1.2345e300) out[0] = v0;
         } else {
@@ -398,7 +404,11 @@ int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t
                      nv1, nv2, nti, ntj, vec_ok)
   // measured at N = 131 072 (steady GB/s by unroll 2 / 4 / 8 / 16): K0 5810 / 5750 / 5640 / 5780, Matern 5440 / 5570 / 5440 / 5470
   constexpr int UNR_DEFAULT = (KID == BGP_KERNEL_BATTGP) ? 2 : 4;
-  if (p.D == 4 && unr == 2) FILL_UNR(2);
+  static const bool t256 = getenv("BGP_FILL_TABLE") && atoi(getenv("BGP_FILL_TABLE")) == 256;  // experiment knob (A/B pending)
+  if (p.D == 4 && t256)
+    hipLaunchKernelGGL((fill_kernel<KID, 4, 4, UNR_DEFAULT>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag,
+                       nv1, nv2, nti, ntj, vec_ok);
+  else if (p.D == 4 && unr == 2) FILL_UNR(2);
   else if (p.D == 4 && unr == 4) FILL_UNR(4);
   else if (p.D == 4 && unr == 8) FILL_UNR(8);
   else if (p.D == 4 && unr == 16) FILL_UNR(16);

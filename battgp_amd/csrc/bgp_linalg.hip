@@ -307,15 +307,52 @@ __device__ __forceinline__ double rsqrt_newton(double p) {
 // diagonal) on exit; every wave executes exactly 64 barriers, in three phases: (A) steps j < C0 update
 // all 16 columns, (B) the 16 steps that own the pivot column, (C) steps j >= C0 + 16 only keep the
 // barrier count
-// LEAN: L(c, j) of the own columns comes out of the one LDS read of column j by v_readlane (scalar registers)
-// instead of 16 more uniform LDS reads (vector registers): same values, 32 VGPRs fewer alive
-struct NoColumnHook {
-  __device__ __forceinline__ void operator()(int, double, double) const {}
-};
-// `done(j, col, d)`: called by the owner wave when column j is final (col = L(lane, j) with d on the diagonal)
-template <int W, bool LEAN = false, typename Done = NoColumnHook>
-__device__ __forceinline__ void chol_cols_reg(double (&a)[16], double (*colbuf)[64], int* sfail, int lane,
-                                              Done done = Done()) {
+template <int W>
+__device__ __forceinline__ void chol_cols(double (*s)[64], double (*colbuf)[64], int* sfail, int lane) {
+  constexpr int NC = 16, C0 = NC * W;
+  double a[NC];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) a[cc] = s[C0 + cc][lane];
+  // (A) a rolled loop is fine here: every register index is static
+#pragma unroll 1
+  for (int j = 0; j < C0; ++j) {
+    __syncthreads();
+    const double* col = colbuf[j & 1];
+    const double lij = col[lane];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) a[cc] = __builtin_fma(-lij, col[C0 + cc], a[cc]);
+  }
+  // (B)
+#pragma unroll
+  for (int jl = 0; jl < NC; ++jl) {
+    const int j = C0 + jl;
+    const double piv = readlane_d(a[jl], j);
+    if (!(piv > 0.0) && lane == 0 && *sfail == 0) *sfail = j + 1;  // also catches NaN; first failing j wins
+    const double rd = rsqrt_newton(piv);
+    double d = piv * rd;
+    d = __builtin_fma(0.5 * rd, __builtin_fma(-d, d, piv), d);  // one correction: d = sqrt(piv)
+    const double lij = (lane > j) ? a[jl] * rd : 0.0;
+    a[jl] = (lane == j) ? d : lij;
+    colbuf[j & 1][lane] = lij;
+    __syncthreads();
+    // my own columns right of j: L(c, j) straight from the owner's registers (no LDS round trip on the
+    // critical path of the next pivot)
+#pragma unroll
+    for (int cc = jl + 1; cc < NC; ++cc) a[cc] = __builtin_fma(-lij, readlane_d(lij, C0 + cc), a[cc]);
+  }
+  // (C)
+#pragma unroll 1
+  for (int j = C0 + NC; j < 64; ++j) __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) s[C0 + cc][lane] = (C0 + cc <= lane) ? a[cc] : 0.0;
+}
+
+// The same column Cholesky for the slim tile kernel: the 16 columns stay in the caller's registers, L(c, j) of the own
+// columns comes out of the one LDS read of column j by v_readlane (scalar registers) instead of 16 more uniform LDS reads
+// (vector registers: 32 VGPRs fewer alive), and `done(j, col, d)` is called by the owner wave the moment column j is
+// final (col = L(lane, j) with d on the diagonal).  Same operations on the same values as chol_cols.
+template <int W, typename Done>
+__device__ __forceinline__ void chol_cols_reg(double (&a)[16], double (*colbuf)[64], int* sfail, int lane, Done done) {
   constexpr int NC = 16, C0 = NC * W;
   // (A) a rolled loop is fine here: every register index is static
 #pragma unroll 1
@@ -324,7 +361,7 @@ __device__ __forceinline__ void chol_cols_reg(double (&a)[16], double (*colbuf)[
     const double* col = colbuf[j & 1];
     const double lij = col[lane];
 #pragma unroll
-    for (int cc = 0; cc < NC; ++cc) a[cc] = __builtin_fma(-lij, LEAN ? readlane_d(lij, C0 + cc) : col[C0 + cc], a[cc]);
+    for (int cc = 0; cc < NC; ++cc) a[cc] = __builtin_fma(-lij, readlane_d(lij, C0 + cc), a[cc]);
   }
   // (B)
 #pragma unroll
@@ -348,17 +385,6 @@ __device__ __forceinline__ void chol_cols_reg(double (&a)[16], double (*colbuf)[
   // (C)
 #pragma unroll 1
   for (int j = C0 + NC; j < 64; ++j) __syncthreads();
-}
-
-template <int W>
-__device__ __forceinline__ void chol_cols(double (*s)[64], double (*colbuf)[64], int* sfail, int lane) {
-  constexpr int NC = 16, C0 = NC * W;
-  double a[NC];
-#pragma unroll
-  for (int cc = 0; cc < NC; ++cc) a[cc] = s[C0 + cc][lane];
-  chol_cols_reg<W>(a, colbuf, sfail, lane);
-#pragma unroll
-  for (int cc = 0; cc < NC; ++cc) s[C0 + cc][lane] = (C0 + cc <= lane) ? a[cc] : 0.0;
 }
 
 // wave W: columns W, W+4, ..., W+60 of X = L^-1
@@ -385,6 +411,42 @@ __device__ __forceinline__ void inv_cols(const double (*s)[64], double* __restri
   }
 #pragma unroll
   for (int cc = 0; cc < NC; ++cc) inv[lane + (W + 4 * cc) * 64] = x[cc];
+}
+
+// the tile kernel below as a device function over caller-provided LDS (s[64][64], colbuf[2][64], sfail), for
+// chain_update_potrf_kernel; the stand-alone kernel keeps its own text so that its measured code does not move
+__device__ __forceinline__ void potrf_tile_body(double* __restrict__ Ajj, int64_t lda, double* __restrict__ inv,
+                                                int* __restrict__ info, int col0, double (*s)[64], double (*colbuf)[64],
+                                                int* sfail) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (*info != 0) return;  // an earlier tile already failed: the whole pipeline is void
+  if (tid == 0) *sfail = 0;
+  // coalesced tile load through LDS.  The strict upper triangle holds don't-care values: they are
+  // updated like everything else but never read as a pivot or broadcast, so they cannot contaminate the factor.
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int r = idx & 63, c = idx >> 6;
+    s[c][r] = Ajj[r + (int64_t)c * lda];
+  }
+  __syncthreads();
+  switch (wave) {
+    case 0: chol_cols<0>(s, colbuf, sfail, lane); break;
+    case 1: chol_cols<1>(s, colbuf, sfail, lane); break;
+    case 2: chol_cols<2>(s, colbuf, sfail, lane); break;
+    default: chol_cols<3>(s, colbuf, sfail, lane); break;
+  }
+  __syncthreads();
+  if (tid == 0 && *sfail != 0) atomicCAS(info, 0, col0 + *sfail);
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int r = idx & 63, c = idx >> 6;
+    if (r >= c) Ajj[r + (int64_t)c * lda] = s[c][r];
+  }
+  switch (wave) {
+    case 0: inv_cols<0>(s, inv, lane); break;
+    case 1: inv_cols<1>(s, inv, lane); break;
+    case 2: inv_cols<2>(s, inv, lane); break;
+    default: inv_cols<3>(s, inv, lane); break;
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(double* __restrict__ Ajj, int64_t lda,
@@ -422,6 +484,89 @@ __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(double* __restrict__
     case 2: inv_cols<2>(s, inv, lane); break;
     default: inv_cols<3>(s, inv, lane); break;
   }
+}
+
+// One launch for {rank-64 update of the rest of the panel block by column step j} + {tile Cholesky of step j + 1}:
+// the workgroup that updates the next diagonal tile (tile (0, 0) of the launch) goes on to factor and invert it while
+// the other workgroups finish their tiles.  The serial chain per 64 columns drops from three dependent launches
+// {potrf, TRSM, update} to two {TRSM, update + potrf}, and the tile Cholesky runs in the shadow of the update instead of
+// behind it.  The tile product is the latency-lean form a k = 64 step allows: BOTH 64 x 64 operand blocks go to LDS in
+// one stage (sixteen 16-byte loads in flight per thread, one barrier), then 16 x 4 MFMAs per wave in the same order over
+// k as gemm_nt_kernel<64, 64, 0>.  Same operations on the same values as the separate kernels (the tile goes through
+// global memory either way): bit-identical.   C[m, n] -= A[m, 64] B[n, 64]^T, lower: tiles with ti >= tj only.
+__global__ __launch_bounds__(256) void chain_update_potrf_kernel(double* C, int64_t ldc, const double* A, int64_t lda,
+                                                                 const double* B, int64_t ldb, int64_t m, int64_t n,
+                                                                 int lower, int* __restrict__ info,
+                                                                 double* __restrict__ inv_next, int col0_next) {
+  constexpr int T = 64, LDS_S = T + 16;
+  __shared__ __attribute__((aligned(16))) double raw[2 * 64 * LDS_S];  // 81 920 B: sA[64][80], sB[64][80]; then the tile
+  __shared__ int sfail;
+  double (*sA)[LDS_S] = reinterpret_cast<double (*)[LDS_S]>(raw);
+  double (*sB)[LDS_S] = reinterpret_cast<double (*)[LDS_S]>(raw + 64 * LDS_S);
+  const int ti = (int)blockIdx.x, tj = (int)blockIdx.y;
+  if ((lower & 1) && ti < tj) return;
+  if (*info != 0) return;
+  const int64_t i0 = (int64_t)ti * T, j0 = (int64_t)tj * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // staging: thread -> rows 2 (tid % 32).., k columns tid / 32 + 8 q (q = 0..7), for A and for B
+  const int rs = (tid & 31) * 2, cs = tid >> 5;
+  const double* gA = A + ((i0 + rs) < m ? (i0 + rs) : 0) + (int64_t)cs * lda;  // out-of-range rows: any valid address
+  const double* gB = B + ((j0 + rs) < n ? (j0 + rs) : 0) + (int64_t)cs * ldb;  // (they only reach unwritten outputs)
+  double2 ra[8], rb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    ra[q] = *reinterpret_cast<const double2*>(gA + (int64_t)(8 * q) * lda);
+    rb[q] = *reinterpret_cast<const double2*>(gB + (int64_t)(8 * q) * ldb);
+  }
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int64_t i = i0 + wi * 32 + b * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + wj * 32 + a * 16 + l4 + 4 * r;
+        acc[a][b][r] = (i < m && j < n) ? C[i + j * ldc] : 0.0;
+      }
+    }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    *reinterpret_cast<double2*>(&sA[cs + 8 * q][rs]) = ra[q];
+    *reinterpret_cast<double2*>(&sB[cs + 8 * q][rs]) = rb[q];
+  }
+  __syncthreads();
+  const int ibase = wi * 32 + l15, jbase = wj * 32 + l15;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int pp = kk * 4 + l4;
+    double fa[2], fb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) fa[a] = sB[pp][jbase + a * 16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) fb[b] = sA[pp][ibase + b * 16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 1);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int64_t i = i0 + wi * 32 + b * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + wj * 32 + a * 16 + l4 + 4 * r;
+        if (i < m && j < n) C[i + j * ldc] = acc[a][b][r];
+      }
+    }
+  if (ti != 0 || tj != 0 || inv_next == nullptr) return;  // (uniform over the workgroup)
+  __syncthreads();  // this workgroup's stores of the tile are visible to all its threads; the operand stages are free
+  potrf_tile_body(C, ldc, inv_next, info, col0_next, reinterpret_cast<double (*)[64]>(raw), reinterpret_cast<double (*)[64]>(raw + 4096),
+                  &sfail);
 }
 
 // ---- "slim" chain kernels: made to fit NEXT TO two resident trailing-update workgroups ----------------
@@ -463,7 +608,7 @@ __device__ __forceinline__ void potrf_slim_body(double* __restrict__ Ajj, int64_
     double a[NC];
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) a[cc] = scalar_ptr(Ajj + (int64_t)(C0 + cc) * lda)[ulane];  // 512 B per column, coalesced
-    chol_cols_reg<W, true>(a, colbuf, sfail, lane, [&](int j, double col, double d) {
+    chol_cols_reg<W>(a, colbuf, sfail, lane, [&](int j, double col, double d) {
       gmem_double* colp = scalar_ptr(Ajj + (int64_t)j * lda);  // (formed by the whole wave, outside the lane condition)
       if (lane >= j) colp[ulane] = col;
       if (j >= 16 && lane > j) lq[slim_lq_off(j) + lane - j - 1] = col;
@@ -1099,6 +1244,21 @@ int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, d
     hipLaunchKernelGGL(potrf_tile_slim_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
   else
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
+  BGP_HIP(h, hipGetLastError());
+  return 0;
+}
+
+// rank-64 update of the rest of the panel block + tile Cholesky (and inverse) of its first diagonal tile, one launch
+int launch_chain_update_potrf(bgp_handle* h, hipStream_t st, double* C, int64_t ldc, const double* A, int64_t lda,
+                              const double* B, int64_t ldb, int64_t m, int64_t n, int lower, int* info, double* inv_next,
+                              int col0_next) {
+  if (m <= 0 || n <= 0) return 0;
+  if ((m & 1) || (n & 1) || (lda & 1) || (ldb & 1) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
+    return bgp_fail(h, -1, "chain_update_potrf: m, n, lda, ldb must be even and the operands 16-byte aligned");
+  const int64_t nti = (m + 63) / 64, ntj = (n + 63) / 64;
+  if (nti > 0x7fffffffLL || ntj > 65535) return bgp_fail(h, -1, "chain_update_potrf: grid too large");
+  hipLaunchKernelGGL(chain_update_potrf_kernel, dim3((unsigned)nti, (unsigned)ntj), dim3(256), 0, st, C, ldc, A, lda, B, ldb, m,
+                     n, lower, info, inv_next, col0_next);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

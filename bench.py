@@ -372,11 +372,11 @@ def schedule_experiments(limit_s: float = 150.0):
     off by default until measured, and nothing they do can reach the record above."""
     import subprocess
 
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "ab_lookahead.py"), "3", "16384", "40000"]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "ab_lookahead.py"), "3", "4096", "16384", "40000"]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
         lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
-        return {"what": "fit+predict ms by lookahead word (1 default, +32 slim chain kernels, +64 split panels), panel scheme 1",
+        return {"what": "fit+predict ms by lookahead word (1 default, +32 slim chain kernels, +64 split panels, +128 fused update + tile Cholesky), panel scheme 1",
                 "rc": r.returncode, "runs": lines, "stderr_tail": r.stderr[-300:] if r.returncode else ""}
     except subprocess.TimeoutExpired:
         return {"rc": "timeout", "runs": []}

@@ -107,7 +107,9 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
  *                    is factored underneath a trailing update uses kernels sized to fit NEXT TO the update's two
  *                    workgroups per CU (<= 64 VGPRs, <= 12 KB LDS) instead of queueing for a CU slot; +64: split
  *                    panels - only the next diagonal block's rows of a panel's solve and look-ahead update stay on
- *                    the panel stream, the tall rest runs on a fourth stream (depth 1, panel scheme 1).
+ *                    the panel stream, the tall rest runs on a fourth stream (depth 1, panel scheme 1); +128: the
+ *                    rank-64 update of a 64-column chain step and the tile Cholesky of the next step share one launch
+ *                    (two dependent launches per 64 columns instead of three).
  *                    Bit-identical results for all. */
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
 

@@ -6,6 +6,8 @@ sanitizer runtime preloaded; every global / LDS / workspace access of the UNMODI
 import os
 import sys
 
+os.environ["BGP_FILL_TABLE"] = "256"  # this process also takes the optional 256-entry interior table of the fill
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
@@ -20,8 +22,8 @@ def main() -> int:
         from battgp_amd.engine import ExactGPEngine
 
         for kid, hyp in ((0, synthetic.HYP_BATTGP), (2, synthetic.HYP_MATERN32)):
-            cases = ((1, 1, 0, 0, 1, 0), (65, 3, 0, 1, 1, 0), (333, 70, 128, 1, 1, 0), (333, 70, 128, 0, 2, 0), (400, 9, 128, 1, 1, 256), (333, 5, 128, 1, 1 | 32 | 64, 0))
-            for n, m, nb, scheme, la, slab in cases if kid == 0 else (cases[2], cases[5]):  # cases[5]: slim chain kernels + split panels
+            cases = ((1, 1, 0, 0, 1, 0), (65, 3, 0, 1, 1, 0), (333, 70, 128, 1, 1, 0), (333, 70, 128, 0, 2, 0), (400, 9, 128, 1, 1, 256), (333, 5, 128, 1, 1 | 32 | 64, 0), (333, 5, 128, 0, 1 | 128, 0))
+            for n, m, nb, scheme, la, slab in cases if kid == 0 else (cases[2], cases[5], cases[6]):  # cases[5]: slim chain kernels + split panels, cases[6]: fused update + potrf
                 x, y = synthetic.make_cell_data(n, seed=5)
                 xq = synthetic.make_query(x, m)
                 e = ExactGPEngine(kid, hyp)

@@ -23,7 +23,7 @@ sys.path.insert(0, HERE)
 import numpy as np  # noqa: E402
 from inject import installed  # noqa: E402
 
-LOOKAHEADS = (0, 1, 2, 1 | 8, 1 | 32, 1 | 64, 1 | 32 | 64)
+LOOKAHEADS = (0, 1, 2, 1 | 8, 1 | 32, 1 | 64, 1 | 32 | 64, 1 | 128, 1 | 64 | 128)
 POLICIES = ["lazy", "eager", "random:1", "random:2"] + [f"prio:{p}" for p in range(24)]
 
 

@@ -26,7 +26,7 @@ def problems(draw, n_max=170, m_max=60, noise_lo=-5.0):
         hyp = [noise, log(-2, 1)] + [log(-0.5, 1) for _ in range(d)]
     opts = dict(
         nb=draw(st.sampled_from([64, 128])), scheme=draw(st.sampled_from([0, 1])),
-        la=draw(st.sampled_from([0, 1, 2, 1 | 8, 1 | 32, 1 | 32 | 64])), slab=draw(st.sampled_from([0, 0, 128])),
+        la=draw(st.sampled_from([0, 1, 2, 1 | 8, 1 | 32, 1 | 32 | 64, 1 | 128, 1 | 32 | 64 | 128])), slab=draw(st.sampled_from([0, 0, 128])),
         sort_time=draw(st.booleans()), dup=draw(st.booleans()), fused=draw(st.booleans()),
     )
     return kid, d, n, m, seed, np.array(hyp), opts

@@ -119,7 +119,8 @@ def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
         _, g_ref = lml_and_grad(kid, hyp, x, y)
         outs = {}
         for scheme in (0, 1):
-            las = (0, 1, 2, 9) + ((1 | 32, 1 | 32 | 64) if scheme == 1 else ())  # + 32: slim chain kernels, + 64: split panels
+            # + 32: slim chain kernels, + 64: split panels, + 128: update + next tile Cholesky in one launch
+            las = (0, 1, 2, 9, 1 | 128) + ((1 | 32, 1 | 32 | 64, 1 | 32 | 64 | 128) if scheme == 1 else ())
             for la in las:
                 e = ExactGPEngine(kid, hyp)
                 e.set_options(nb_outer=128, lookahead=la)
@@ -135,7 +136,7 @@ def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
                     assert res[0] < 1e-7 and res[1] < 1e-12
                 e.close()
             base = outs[(scheme, 0)]
-            for la in las[1:]:  # look-ahead, slim chain kernels, split panels: never a bit
+            for la in las[1:]:  # look-ahead, slim chain kernels, split panels, fused launches: never a bit
                 assert outs[(scheme, la)][0] == base[0]
                 assert np.array_equal(outs[(scheme, la)][1], base[1]) and np.array_equal(outs[(scheme, la)][2], base[2])
             assert abs(base[0] - ref.lml) < 1e-9 * abs(ref.lml)
@@ -153,6 +154,35 @@ def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
         e.close()
         assert lml_s == outs[(1, 1)][0] and np.array_equal(mean_s, outs[(1, 1)][1]) and np.array_equal(var_s, outs[(1, 1)][2])
         assert np.max(np.abs(g_s - g_ref) / np.abs(g_ref)) < 1e-7
+
+
+def test_failed_pivot_inside_the_fused_launch_walks_the_jitter_ladder(emu):
+    """a pivot that fails inside chain_update_potrf_kernel (lookahead bit 7) must be reported like one that fails in the
+    stand-alone tile kernel: same jitter rung, same LML, and NotPSD when the ladder is exhausted"""
+    from battgp_amd.engine import ExactGPEngine, NotPSDError, NumericalWarning
+    from oracle import kernels as K
+
+    rng = np.random.default_rng(5)
+    n = 300
+    x = rng.normal(size=(n, 2))
+    x[150:] = x[:150]  # every point twice and no noise: singular beyond the first 150 pivots (tiles 2, 3, 4 of a 64-wide chain)
+    y = rng.normal(size=n)
+    hyp = np.array([0.0, 1.0, 1.0, 1.0])  # ARD-RBF, sigma^2 = 0
+    got = []
+    for la in (1, 1 | 128):
+        for scheme in (0, 1):
+            e = ExactGPEngine(K.KERNEL_ARD_RBF, hyp)
+            e.set_options(nb_outer=128, lookahead=la)
+            e.set_panel_scheme(scheme)
+            with pytest.warns(NumericalWarning):
+                lml = e.fit(x, y)
+            got.append((la, scheme, e.jitter, lml))
+            e.set_options(max_tries=0)
+            with pytest.raises(NotPSDError):
+                e.fit(x, y)
+            e.close()
+    assert all(g[2] == got[0][2] > 0.0 for g in got), got
+    assert got[0][3] == got[2][3] and got[1][3] == got[3][3], got  # fused == unfused, per scheme, to the last bit
 
 
 def test_slab_layout_and_full_covariance(S):

@@ -500,7 +500,8 @@ def test_panel_schemes_agree_and_match_oracle(kid, n, nb):
 def test_slim_chain_kernels_and_split_panels_are_bit_identical(kid, n, nb):
     """lookahead bit 5: the diagonal-block chain of every panel after the first runs on the kernels sized to fit next
     to the trailing update's workgroups (potrf_tile_slim, chain_gemm_slim, 32-wide diag_out); bit 6: the panel's solve
-    and look-ahead update are split into the next diagonal block's rows (panel stream) and the tall rest (bulk stream).
+    and look-ahead update are split into the next diagonal block's rows (panel stream) and the tall rest (bulk stream);
+    bit 7: the rank-64 update of a chain step and the tile Cholesky of the next step share one launch.
     Same arithmetic in the same order for every element, so factor, LML, posterior and tile inverses are identical to
     the last bit - which at N = 20 000 (a trailing update that really saturates the GPU, four streams in flight) is also
     the test of the event graph that orders the streams"""
@@ -508,7 +509,7 @@ def test_slim_chain_kernels_and_split_panels_are_bit_identical(kid, n, nb):
     x, y = synthetic.make_cell_data(n, seed=n + 1)
     xq = synthetic.make_query(x, 200)
     out = []
-    for la in (1, 1 | 32, 1 | 64, 1 | 32 | 64):
+    for la in (1, 1 | 32, 1 | 64, 1 | 32 | 64, 1 | 128, 1 | 64 | 128):
         e = ExactGPEngine(kid, hyp)
         e.set_options(nb_outer=nb, lookahead=la)
         e.set_panel_scheme(1)

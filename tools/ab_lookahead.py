@@ -1,4 +1,4 @@
-"""A/B of the optional schedules of the blocked Cholesky (lookahead word: +32 slim chain kernels, +64 split panels)
+"""A/B of the optional schedules of the blocked Cholesky (lookahead word: +32 slim chain kernels, +64 split panels, +128 update + next tile Cholesky in one launch)
 against the default, at the sizes where the panel chain matters.  One JSON line per (N, lookahead); bench.py runs this
 in a child process with a time limit and files the lines under "experiments" (a schedule that has never met the GPU
 must not be able to take the headline measurement down with it).
@@ -28,7 +28,7 @@ for n in sizes:
     tv = torch.empty(m, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     base = None
-    for la in (1, 1 | 32, 1 | 64, 1 | 32 | 64):
+    for la in (1, 1 | 32, 1 | 64, 1 | 32 | 64, 1 | 128, 1 | 64 | 128):
         eng = ExactGPEngine(KERNEL_BATTGP, synthetic.HYP_BATTGP, device=0)
         eng.set_options(lookahead=la)
         eng.set_panel_scheme(1)

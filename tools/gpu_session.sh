@@ -40,10 +40,11 @@ if has sweep; then
   BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 1024 2048 4096 8192 16384 32768 40000 65536 > $OUT/sweep_n.jsonl 2> $OUT/sweep_n.err
 fi
 if has slim; then
-  stamp "slim chain kernels (+32) and split panels (+64) A/B, scheme 1"
-  for la in 1 33 65 97; do
-    BGP_LA=$la BGP_SCHEME=1 BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 8192 16384 24576 32768 40000 65536 > $OUT/sweep_la$la.jsonl 2>> $OUT/sweep_n.err
+  stamp "slim chain kernels (+32), split panels (+64), fused update + tile Cholesky (+128): A/B, scheme 1"
+  for la in 1 33 65 97 129 193; do
+    BGP_LA=$la BGP_SCHEME=1 BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 4096 8192 16384 24576 32768 40000 65536 > $OUT/sweep_la$la.jsonl 2>> $OUT/sweep_n.err
   done
+  for la in 1 129; do BGP_LA=$la BGP_ONLY=battgp timeout 300 python tools/sweep_n.py 9 1024 2048 4096 8192 > $OUT/sweep_small_la$la.jsonl 2>> $OUT/sweep_n.err; done
   (cd /tmp && BGP_LA=97 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl16k_slim -o tl -- \
      python $REPO/tools/profile_workload.py 16384 battgp 3 > $OUT/tl16k_slim.log 2>&1)
   python tools/timeline.py $(find $OUT/tl16k_slim -name '*kernel_trace.csv' | head -1) > $OUT/tl16k_slim_summary.txt 2>&1
@@ -61,6 +62,7 @@ fi
 if has fill; then
   stamp "steady fill"
   timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate.txt 2>&1
+  BGP_FILL_TABLE=256 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_table256.txt 2>&1
 fi
 if has sharded; then
   stamp "sharded driver, single-rank proxy"
