@@ -155,9 +155,9 @@ int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t nrows, int64_
       const int64_t ncols = K0 + nbk - (j + BGP_IB);
       if (ncols > 0) {
         double* A22 = A + (j + BGP_IB) + (j + BGP_IB) * lda;
-        if (fuse && !slim && ((rows_below + 63) / 64) * (ncols / 64) <= 1536) {
+        if (fuse && ((rows_below + 63) / 64) * (ncols / 64) <= 1536) {
           rc = launch_chain_update_potrf(h, st, A22, lda, A21, lda, A21, lda, rows_below, ncols, 1, dinfo, inv_j + BGP_IB * BGP_IB,
-                                         (int)(j + BGP_IB + gofs));
+                                         (int)(j + BGP_IB + gofs), slim ? 1 : 0);
           tile_done = true;
         } else {
           rc = slim ? launch_chain_gemm_slim(h, st, 0, A22, lda, A21, lda, A21, lda, rows_below, ncols, 1, dinfo)

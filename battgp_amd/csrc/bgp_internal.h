@@ -155,7 +155,7 @@ int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, d
                       int* info, int col0, int slim = 0);
 int launch_chain_update_potrf(bgp_handle* h, hipStream_t st, double* C, int64_t ldc, const double* A, int64_t lda,
                               const double* B, int64_t ldb, int64_t m, int64_t n, int lower, int* info, double* inv_next,
-                              int col0_next);
+                              int col0_next, int slim = 0);
 int launch_chain_gemm_slim(bgp_handle* h, hipStream_t st, int mode, double* C, int64_t ldc, const double* A, int64_t lda,
                            const double* B, int64_t ldb, int64_t m, int64_t n, int lower, const int* abort_flag);
 int launch_fit_scalars(bgp_handle* h, hipStream_t st, const SlabView& A, const double* z,

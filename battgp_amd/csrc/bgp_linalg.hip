@@ -664,39 +664,50 @@ __device__ __forceinline__ void potrf_slim_body(double* __restrict__ Ajj, int64_
   for (int cc = 0; cc < NC; ++cc) scalar_ptr(inv + (W + 4 * cc) * 64)[ulane] = x[cc];
 }
 
-__global__ __launch_bounds__(256) BGP_WAVES_PER_EU(8)
-void potrf_tile_slim_kernel(double* __restrict__ Ajj, int64_t lda, double* __restrict__ inv, int* __restrict__ info,
-                            int col0) {
-  __shared__ double colbuf[2][64];  // the scaled pivot column of the current step
-  __shared__ double lq[SLIM_LQ];    // columns 16..63 of L, rows below the diagonal, packed: the inverse reads them
-  __shared__ double srd[64];        // 1 / L_pp
-  __shared__ int sfail;
+constexpr int SLIM_POTRF_LDS = 2 * 64 + SLIM_LQ + 64;  // doubles: colbuf[2][64], lq, srd
+// the whole slim tile kernel over caller-provided LDS (SLIM_POTRF_LDS doubles + an int)
+__device__ __forceinline__ void potrf_slim_tile(double* __restrict__ Ajj, int64_t lda, double* __restrict__ inv,
+                                                int* __restrict__ info, int col0, double* lds, int* sfail) {
+  double (*colbuf)[64] = reinterpret_cast<double (*)[64]>(lds);  // the scaled pivot column of the current step
+  double* lq = lds + 2 * 64;        // columns 16..63 of L, rows below the diagonal, packed: the inverse reads them
+  double* srd = lq + SLIM_LQ;       // 1 / L_pp
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (*info != 0) return;
-  if (tid == 0) sfail = 0;
+  if (tid == 0) *sfail = 0;
   __syncthreads();
   switch (wave) {
-    case 0: potrf_slim_body<0>(Ajj, lda, inv, colbuf, lq, srd, &sfail, info, col0, lane); break;
-    case 1: potrf_slim_body<1>(Ajj, lda, inv, colbuf, lq, srd, &sfail, info, col0, lane); break;
-    case 2: potrf_slim_body<2>(Ajj, lda, inv, colbuf, lq, srd, &sfail, info, col0, lane); break;
-    default: potrf_slim_body<3>(Ajj, lda, inv, colbuf, lq, srd, &sfail, info, col0, lane); break;
+    case 0: potrf_slim_body<0>(Ajj, lda, inv, colbuf, lq, srd, sfail, info, col0, lane); break;
+    case 1: potrf_slim_body<1>(Ajj, lda, inv, colbuf, lq, srd, sfail, info, col0, lane); break;
+    case 2: potrf_slim_body<2>(Ajj, lda, inv, colbuf, lq, srd, sfail, info, col0, lane); break;
+    default: potrf_slim_body<3>(Ajj, lda, inv, colbuf, lq, srd, sfail, info, col0, lane); break;
   }
+}
+
+__global__ __launch_bounds__(256) BGP_WAVES_PER_EU(8)
+void potrf_tile_slim_kernel(double* __restrict__ Ajj, int64_t lda, double* __restrict__ inv, int* __restrict__ info,
+                            int col0) {
+  __shared__ double lds[SLIM_POTRF_LDS];
+  __shared__ int sfail;
+  potrf_slim_tile(Ajj, lda, inv, info, col0, lds, &sfail);
 }
 
 // The k = 64 products of the chain on 64 x 64 tiles:  MODE 0  C -= A B^T (`lower`: tiles with ti >= tj only),
 // MODE 1  C = A B^T (C may alias A: TRSM by the inverted tile).  Same fragment layout and the same order of MFMAs
 // over k as gemm_nt_kernel<64, 64, MODE> (bit-identical), but 8-deep single-buffered stages: 10 KB of LDS.
+constexpr int SLIM_GEMM_LDS = 2 * 8 * (64 + 16);  // doubles: sA[8][80], sB[8][80]
+// the tile product over caller-provided LDS (SLIM_GEMM_LDS doubles); false when the block has no tile / the pipeline
+// is aborted
 template <int MODE>
-__global__ __launch_bounds__(256) BGP_WAVES_PER_EU(8)
-void chain_gemm_slim_kernel(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
-                            int64_t m, int64_t n, int lower, const int* __restrict__ abort_flag) {
+__device__ __forceinline__ bool chain_gemm_slim_tile(double* lds, double* C, int64_t ldc, const double* A, int64_t lda,
+                                                     const double* B, int64_t ldb, int64_t m, int64_t n, int lower,
+                                                     const int* __restrict__ abort_flag) {
   constexpr int T = 64, SBK = 8, LDS_S = T + 16, KTOT = 64;
-  __shared__ __attribute__((aligned(16))) double sA[SBK][LDS_S];
-  __shared__ __attribute__((aligned(16))) double sB[SBK][LDS_S];
+  double (*sA)[LDS_S] = reinterpret_cast<double (*)[LDS_S]>(lds);
+  double (*sB)[LDS_S] = reinterpret_cast<double (*)[LDS_S]>(lds + SBK * LDS_S);
   const int ti = (int)blockIdx.x, tj = (int)blockIdx.y;  // 2-D grid: tile indices arrive in scalar registers
-  if ((lower & 1) && ti < tj) return;
-  if (abort_flag != nullptr && *abort_flag != 0) return;
+  if ((lower & 1) && ti < tj) return false;
+  if (abort_flag != nullptr && *abort_flag != 0) return false;
   const int64_t i0 = (int64_t)ti * T, j0 = (int64_t)tj * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave & 1, wj = wave >> 1;
@@ -757,6 +768,31 @@ void chain_gemm_slim_kernel(double* C, int64_t ldc, const double* A, int64_t lda
         gmem_double* cp = scalar_ptr(C + (i0 + b * 16) + (j0 + a * 16 + 4 * r) * ldc);
         if (i_in[b] && j < n) cp[coff] = acc[a][b][r];
       }
+  return true;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) BGP_WAVES_PER_EU(8)
+void chain_gemm_slim_kernel(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
+                            int64_t m, int64_t n, int lower, const int* __restrict__ abort_flag) {
+  __shared__ __attribute__((aligned(16))) double lds[SLIM_GEMM_LDS];
+  chain_gemm_slim_tile<MODE>(lds, C, ldc, A, lda, B, ldb, m, n, lower, abort_flag);
+}
+
+// slim rank-64 update + slim tile Cholesky of the launch's tile (0, 0) (chain_update_potrf_kernel's counterpart for a
+// chain that runs underneath a trailing update: still <= 64 VGPRs and ~10.6 KB of LDS, and one slot acquisition less
+// per 64 columns)
+__global__ __launch_bounds__(256) BGP_WAVES_PER_EU(8)
+void chain_update_potrf_slim_kernel(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
+                                    int64_t m, int64_t n, int lower, int* __restrict__ info, double* __restrict__ inv_next,
+                                    int col0_next) {
+  constexpr int NLDS = SLIM_GEMM_LDS > SLIM_POTRF_LDS ? SLIM_GEMM_LDS : SLIM_POTRF_LDS;
+  __shared__ __attribute__((aligned(16))) double lds[NLDS];
+  __shared__ int sfail;
+  const bool did = chain_gemm_slim_tile<0>(lds, C, ldc, A, lda, B, ldb, m, n, lower, info);
+  if (!did || blockIdx.x != 0 || blockIdx.y != 0) return;  // (uniform over the workgroup)
+  __syncthreads();  // the tile's stores are visible to the whole workgroup; the operand stages are free
+  potrf_slim_tile(C, ldc, inv_next, info, col0_next, lds, &sfail);
 }
 
 // ---- explicit inverses of ALL diagonal panel blocks of a factor, in one launch ---------------------
@@ -1251,14 +1287,18 @@ int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, d
 // rank-64 update of the rest of the panel block + tile Cholesky (and inverse) of its first diagonal tile, one launch
 int launch_chain_update_potrf(bgp_handle* h, hipStream_t st, double* C, int64_t ldc, const double* A, int64_t lda,
                               const double* B, int64_t ldb, int64_t m, int64_t n, int lower, int* info, double* inv_next,
-                              int col0_next) {
+                              int col0_next, int slim) {
   if (m <= 0 || n <= 0) return 0;
   if ((m & 1) || (n & 1) || (lda & 1) || (ldb & 1) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
     return bgp_fail(h, -1, "chain_update_potrf: m, n, lda, ldb must be even and the operands 16-byte aligned");
   const int64_t nti = (m + 63) / 64, ntj = (n + 63) / 64;
   if (nti > 0x7fffffffLL || ntj > 65535) return bgp_fail(h, -1, "chain_update_potrf: grid too large");
-  hipLaunchKernelGGL(chain_update_potrf_kernel, dim3((unsigned)nti, (unsigned)ntj), dim3(256), 0, st, C, ldc, A, lda, B, ldb, m,
-                     n, lower, info, inv_next, col0_next);
+  if (slim)
+    hipLaunchKernelGGL(chain_update_potrf_slim_kernel, dim3((unsigned)nti, (unsigned)ntj), dim3(256), 0, st, C, ldc, A, lda, B,
+                       ldb, m, n, lower, info, inv_next, col0_next);
+  else
+    hipLaunchKernelGGL(chain_update_potrf_kernel, dim3((unsigned)nti, (unsigned)ntj), dim3(256), 0, st, C, ldc, A, lda, B, ldb, m,
+                       n, lower, info, inv_next, col0_next);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }
