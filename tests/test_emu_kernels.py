@@ -235,3 +235,53 @@ def test_stream_graph_under_adversarial_schedules(emu):
             assert G.run_policy(emu, policy, las, ref) == [], policy
     finally:
         emu.hipemu_set_sched(b"sync")
+
+
+@pytest.mark.parametrize("world,sched", [(2, "prio:9"), (3, "lazy")])
+def test_sharded_device_backend_ranks_on_the_cpu_build(world, sched):
+    """tests/test_gpu_sharded.py's multi-rank worker (DeviceBackend: the engine's per-panel C-ABI building blocks driven
+    by sharded.py, gloo between the ranks) with every rank on the CPU build and its streams deferred (HIPEMU_SCHED): the
+    packing, offsets, look-ahead exchange and stream hand-offs of the multi-GPU schedule against the oracle, without a GPU"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    if HERE not in sys.path:
+        sys.path.insert(0, HERE)
+    import test_gpu_sharded as G  # by its real name: the spawned ranks unpickle the worker by module
+
+    from battgp_amd import synthetic
+    from oracle import kernels as K
+    from oracle.exact_gp import OracleGP
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n, nb = 450, 64
+    saved = {k: os.environ.get(k) for k in ("BGP_TEST_EMU", "HIPEMU_SCHED")}
+    os.environ.update(BGP_TEST_EMU="1", HIPEMU_SCHED=sched)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=G._two_rank_worker, args=(r, world, port, n, nb, q)) for r in range(world)]
+        [p.start() for p in procs]
+        res = sorted(q.get(timeout=400) for _ in range(world))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    x, y = synthetic.make_cell_data(n, seed=9)
+    xq = synthetic.make_query(x, 33)
+    ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
+    m_ref, v_ref = ref.predict(xq)
+    for rank, lml, mean, var in res:
+        assert abs(lml - ref.lml) < 1e-6 * abs(ref.lml)
+        assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
+        assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+    assert all(r[1:] == res[0][1:] for r in res)

@@ -76,6 +76,14 @@ def _two_rank_worker(rank, world, port, n, nb, q):
     # both ranks share the one GPU of the test box; gloo moves the device buffers (RCCL refuses two ranks
     # on one device) - the schedule, packing and offsets are exactly those of the multi-GPU run
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if os.environ.get("BGP_TEST_EMU") == "1":
+        # tests/test_emu_kernels.py: the same ranks on the CPU build of the kernel sources (test infrastructure; the
+        # "device" buffers are host memory, the streams follow HIPEMU_SCHED)
+        sys.path.insert(0, os.path.join(root, "tests", "emu"))
+        from inject import fake_cuda_tensors, installed
+
+        fake_cuda_tensors()
+        installed().__enter__()
     from battgp_amd import parallel, synthetic
     from battgp_amd.sharded import make_sharded_gp
 
