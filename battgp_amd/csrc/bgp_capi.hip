@@ -138,11 +138,14 @@ struct PhaseTimer {
 // `slim`: the chain kernels that fit next to two resident trailing-update workgroups (bgp_linalg.hip);
 // `fuse`: the rank-64 update of step j and the tile Cholesky of step j + 1 in one launch (two dependent launches per
 // 64 columns instead of three; while the update is at most ~1500 tiles).  Same results either way.
+// `inv_ofs`: index origin of the tile inverses (default: the same global origin `gofs` as the failing-minor report; the
+// sharded driver keeps panel-local inverses and reports globally).
 int factor_panel(bgp_handle* h, hipStream_t st, double* A, int64_t nrows, int64_t lda, double* inv, int* dinfo,
-                 int64_t K0, int64_t nbk, int64_t gofs = 0, bool slim = false, bool fuse = false) {
+                 int64_t K0, int64_t nbk, int64_t gofs = 0, bool slim = false, bool fuse = false, int64_t inv_ofs = -1) {
+  if (inv_ofs < 0) inv_ofs = gofs;
   bool tile_done = false;  // the diagonal tile of this step was factored by the previous step's fused launch
   for (int64_t j = K0; j < K0 + nbk; j += BGP_IB) {
-    double* inv_j = inv + ((j + gofs) / BGP_IB) * (BGP_IB * BGP_IB);
+    double* inv_j = inv + ((j + inv_ofs) / BGP_IB) * (BGP_IB * BGP_IB);
     int rc = tile_done ? 0 : launch_potrf_tile(h, st, A + j + j * lda, lda, inv_j, dinfo, (int)(j + gofs), slim ? 1 : 0);
     if (rc) return rc;
     tile_done = false;
@@ -1617,17 +1620,9 @@ int bgp_factor_pack_panel_async_dev(bgp_handle* h, double* panel_dev, int64_t ld
   const int64_t ldd = 2 * NB, below = nrows - nbk;
   // tile inverses are indexed by the panel-local tile (inv_dev belongs to this panel); the failing minor globally
   if ((rc = launch_diag_in(h, st, panel_dev, ld, h->dD, ldd, nbk))) return rc;
-  for (int64_t j = 0; j < nbk; j += BGP_IB) {  // factor_panel with a global report offset but panel-local inverses
-    double* inv_j = inv_dev + (j / BGP_IB) * (BGP_IB * BGP_IB);
-    if ((rc = launch_potrf_tile(h, st, h->dD + j + j * ldd, ldd, inv_j, h->dinfo, (int)(j + gofs)))) return rc;
-    const int64_t rows_below = 2 * (int64_t)nbk - (j + BGP_IB);
-    double* A21 = h->dD + (j + BGP_IB) + j * ldd;
-    if ((rc = launch_gemm_nt(h, st, 1, 64, A21, ldd, A21, ldd, inv_j, BGP_IB, rows_below, BGP_IB, BGP_IB, 0, h->dinfo))) return rc;
-    const int64_t ncols = nbk - (j + BGP_IB);
-    if (ncols > 0 && (rc = launch_gemm_nt(h, st, 0, 128, h->dD + (j + BGP_IB) + (j + BGP_IB) * ldd, ldd, A21, ldd, A21, ldd,
-                                          rows_below, ncols, BGP_IB, 1, h->dinfo)))
-      return rc;
-  }
+  // global report offset, panel-local inverses; lookahead bit 7: update + next tile Cholesky in one launch
+  if ((rc = factor_panel(h, st, h->dD, 2 * (int64_t)nbk, ldd, inv_dev, h->dinfo, 0, nbk, gofs, false, (h->lookahead & 128) != 0, 0)))
+    return rc;
   if ((rc = launch_diag_out(h, st, h->dD, ldd, panel_dev, ld, h->dLinv, NB, nbk))) return rc;
   if ((rc = launch_copy_panel(h, st, panel_dev, ld, pack_dev, nrows, nbk, nbk))) return rc;
   if (below > 0) {
