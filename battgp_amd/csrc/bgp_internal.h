@@ -60,6 +60,8 @@ struct bgp_handle {
   int device = 0;
   hipStream_t s_main = nullptr, s_aux = nullptr, s_copy = nullptr, s_bulk = nullptr;  // s_bulk: tall parts of a split panel (lookahead bit 6)
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  std::vector<hipEvent_t> ev_phase; // one begin / end pair per phase-timer slot (PhaseTimer)
+  uint32_t phase_pending = 0, phase_acc = 0;  // slots whose end event is recorded but not read yet / that accumulate
   std::vector<hipEvent_t> ev_pool;  // timing pairs around trailing updates
   std::vector<hipEvent_t> ev_sync;  // cross-stream dependencies of the look-ahead schedule
   // kernel
