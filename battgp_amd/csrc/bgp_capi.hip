@@ -330,8 +330,12 @@ int ensure_panel_ws(bgp_handle* h, int64_t nrows, int64_t NB, int nbuf) {
 // diagonal and come out as (L^-1 y)^T - the forward solve costs no launch of its own.
 // The matrix lives in column slabs (SlabView): a trailing update is one launch per slab it touches
 // (one launch in the full-square layout); panels never straddle a slab.
+// `deferred` != nullptr: the streams are joined into st ON THE DEVICE and the failure flag's copy is enqueued, but the
+// host does not wait: the caller enqueues what follows (solve, scalars) behind it, reads h->hinfo[0] behind its own
+// synchronisation of st and then calls deferred->finish() (after a failed factorisation the later kernels compute
+// garbage that is discarded).
 int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, int64_t nrows, double* inv,
-                 int* dinfo, int* info_out, bool time_trailing) {
+                 int* dinfo, int* info_out, bool time_trailing, TrailTimer* deferred = nullptr) {
   const int64_t NB = h->nb_outer;
   const int64_t extra = nrows - n;
   if (V.W < n && (V.W % NB) != 0)
@@ -538,6 +542,24 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
     if (cr < n && (rc = update(st, tmode_of(nbk), src[step], cr, n))) return rc;
     if ((rc = step_event(step, 2, &ev))) return rc;
     BGP_HIP(h, hipEventRecord(ev, st));
+  }
+  if (deferred) {
+    // join on the device: st continues behind the last work of the panel, copy and bulk streams
+    if (la) {
+      BGP_HIP(h, hipEventRecord(h->ev_a, sp));
+      BGP_HIP(h, hipStreamWaitEvent(st, h->ev_a, 0));
+    }
+    if (dmode) {
+      BGP_HIP(h, hipEventRecord(h->ev_b, sc));
+      BGP_HIP(h, hipStreamWaitEvent(st, h->ev_b, 0));
+    }
+    if (split) {
+      BGP_HIP(h, hipEventRecord(h->ev_c, sb));
+      BGP_HIP(h, hipStreamWaitEvent(st, h->ev_c, 0));
+    }
+    BGP_HIP(h, hipMemcpyAsync(h->hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, st));
+    *deferred = tt;
+    return 0;
   }
   if (split) BGP_HIP(h, hipStreamSynchronize(sb));
   if (dmode) BGP_HIP(h, hipStreamSynchronize(sc));
@@ -808,12 +830,30 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mri
       }
       if ((rc = t.stop_async())) return rc;
     }
+    TrailTimer tt{h, false};
     {
+      // the factorisation is only ENQUEUED (streams joined into st on the device, flag copy behind them) ...
       PhaseTimer t(h, st, BGP_T_POTRF, true);
-      rc = potrf_driver(h, st, V, Npad, Npad + h->aug_used, h->dInv, h->dinfo, &info, true);
+      rc = potrf_driver(h, st, V, Npad, Npad + h->aug_used, h->dInv, h->dinfo, &info, true, &tt);
       if (rc) return rc;
+      if ((rc = t.stop_async())) return rc;
+    }
+    {
+      // ... and so is what follows it; ONE host synchronisation per attempt reads the flag and the scalars together
+      PhaseTimer t(h, st, BGP_T_SOLVE);
+      // z^T = row Npad of the factor (came out of the factorisation); alpha = L^-T z is computed
+      // lazily (ensure_alpha) - the predictive path with variance never needs it
+      for (int64_t c0 = 0; c0 < Npad;) {
+        const int64_t c1 = V.slab_end(c0, Npad);
+        if ((rc = launch_gather_row(h, st, V.at(Npad, c0), V.ld(c0), c1 - c0, h->dz + c0))) return rc;
+        c0 = c1;
+      }
+      if ((rc = launch_fit_scalars(h, st, V, h->dz, 1, Npad, h->dscal))) return rc;
+      BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
       if ((rc = t.stop())) return rc;
     }
+    info = *h->hinfo;
+    if ((rc = tt.finish())) return rc;
     if (info == 0) break;
     if (attempt == h->max_tries) break;
     jitter = h->jitter0 * pow(10.0, (double)attempt);
@@ -824,20 +864,6 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mri
     return info > 0 ? info : -4;
   }
   h->jitter_used = jitter;
-  {
-    PhaseTimer t(h, st, BGP_T_SOLVE);
-    int rc;
-    // z^T = row Npad of the factor (came out of the factorisation); alpha = L^-T z is computed
-    // lazily (ensure_alpha) - the predictive path with variance never needs it
-    for (int64_t c0 = 0; c0 < Npad;) {
-      const int64_t c1 = V.slab_end(c0, Npad);
-      if ((rc = launch_gather_row(h, st, V.at(Npad, c0), V.ld(c0), c1 - c0, h->dz + c0))) return rc;
-      c0 = c1;
-    }
-    if ((rc = launch_fit_scalars(h, st, V, h->dz, 1, Npad, h->dscal))) return rc;
-    BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    if ((rc = t.stop())) return rc;
-  }
   const double logdet_half = h->hscal[0], zz = h->hscal[1];
   h->lml = -0.5 * zz - logdet_half - 0.5 * (double)N * log(2.0 * M_PI);
   h->fitted = true;
