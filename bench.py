@@ -110,8 +110,95 @@ def cpu_baseline(kernel_name: str, n_cpu: int, m: int) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# committed profile evidence (rocprofv3 PMC passes can not run inside the bench)
+# PMC evidence: collected live by child rocprofv3 passes of this workload (pmc_live), else the committed passes
 # ---------------------------------------------------------------------------------------------------------------
+TRAIL_FRAG = "gemm_nt_kernel<128, 128, 2"  # the rank-NB trailing update in rocprofv3's kernel names
+
+
+def pmc_live(n: int, kernel: str, m: int = 300, limit_s: float = 240.0) -> dict:
+    """HBM traffic and MFMA utilisation of the trailing update at THIS run's workload: rocprofv3 --pmc passes over
+    tools/profile_workload.py (one fused fit+predict + alpha()) in child processes, one counter group per pass
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domain next to --pmc), each with a time limit.
+    Corrections as MI355X_MICROARCH.md (HBM section) prescribes: the counters are KiB; on gfx950 FETCH_SIZE tallies a
+    wide coalesced read at half its bytes (x2).  Calibrated inside the same passes on two known byte counts:
+    gemv_t_partial reads the strictly-lower panels of L exactly once, the fill writes 4N(N+1) + 8MN bytes once."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = os.environ.get("BGP_ROCPROFV3") or shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"rc": "rocprofv3 not found"}
+    work = tempfile.mkdtemp(prefix="bgp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))  # kernel -> counter -> [dispatches, sum]
+    span = collections.defaultdict(float)  # kernel -> summed dispatch duration (ns) of the MFMA pass
+    passes = {}
+    try:
+        for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+                              ("mfma", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])):
+            d = os.path.join(work, tag)
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "profile_workload.py"), str(n), kernel]
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=limit_s)
+                passes[tag] = {"rc": r.returncode, "s": time.perf_counter() - t0}
+                if r.returncode:
+                    passes[tag]["stderr_tail"] = r.stderr[-300:]
+            except subprocess.TimeoutExpired:
+                passes[tag] = {"rc": "timeout", "s": limit_s}
+                continue
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        a = agg[row["Kernel_Name"]][row["Counter_Name"]]
+                        a[0] += 1
+                        a[1] += float(row["Counter_Value"])
+                        if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                            span[row["Kernel_Name"]] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+    def pick(frag, counter):
+        ks = [k for k in agg if frag in k and counter in agg[k]]
+        return sum(agg[k][counter][0] for k in ks), sum(agg[k][counter][1] for k in ks)
+
+    kib, xccs, simds = 1024.0, 8, 1024
+    npad = (n + 63) // 64 * 64
+    nb = 1024 if npad >= 32768 else 512  # the engine's automatic outer panel width (apply_auto_nb)
+    calls_f, fetch = pick(TRAIL_FRAG, "FETCH_SIZE")
+    calls_w, write = pick(TRAIL_FRAG, "WRITE_SIZE")
+    _, busy = pick(TRAIL_FRAG, "SQ_VALU_MFMA_BUSY_CYCLES")
+    _, gui = pick(TRAIL_FRAG, "GRBM_GUI_ACTIVE")
+    dur_ns = sum(v for k, v in span.items() if TRAIL_FRAG in k)
+    gemv_expected = sum(8.0 * (npad - min(k0 + nb, npad)) * (min(k0 + nb, npad) - k0) for k0 in range(0, npad, nb))
+    _, gemv_fetch = pick("gemv_t_partial_kernel", "FETCH_SIZE")
+    _, fill_write = pick("fill_kernel", "WRITE_SIZE")
+    out = {"passes": passes, "workload": f"tools/profile_workload.py {n} {kernel}: one fused fit+predict (M = {m}) + alpha()"}
+    if calls_f and calls_w:
+        out.update({
+            "dispatches": calls_f,
+            "fetch_bytes_corrected_per_dispatch": fetch * kib * 2.0 / calls_f,
+            "write_bytes_per_dispatch": write * kib / calls_w,
+            "hbm_bytes_per_dispatch": fetch * kib * 2.0 / calls_f + write * kib / calls_w,
+            "hbm_bytes_total": fetch * kib * 2.0 + write * kib,
+            # every trailing element read and written once per outer panel (the atomic-add epilogue): 2 * 8 * N^3 / (3 NB) / 2
+            "algorithmic_c_traffic_bytes_total": 2 * 4.0 * n**3 / (3 * nb),
+            "calibration": {
+                "fetch_raw_over_expected_gemv_t (0.5 = the guide's x2 correction holds)": gemv_fetch * kib / gemv_expected if gemv_expected else None,
+                "fill_write_over_algorithmic": fill_write * kib / (4.0 * n * (n + 1) + 8.0 * m * n),
+            },
+        })
+    if gui:
+        out["mfma_util"] = busy / (gui / xccs * simds)
+        out["effective_clock_ghz_under_pmc"] = (gui / xccs) / dur_ns if dur_ns else None
+    return out
+
+
 def profile_summary(n: int, kernel: str):
     for tag in (PROFILE_TAG, "r01"):
         for name in (f"{tag}_n{n}_{kernel}_summary.json", f"{tag}_n{n}_summary.json" if kernel == "battgp" else None):
@@ -335,35 +422,65 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
         }
     wl.eng.close()  # frees (or parks) the factor before the scratch-sized side measurements
     if rank == 0 and world == 1 and not args.no_extras:
-        # steady rate of the fill kernel and the memset ceiling, beside the in-situ figure
-        wl2 = CellWorkload(n, m, args.kernel, local_rank, n, args)
         from battgp_amd.engine import trim_pool
 
-        trim_pool(local_rank)
-        out["roofline_fill"]["steady_gbs"] = wl2.fill_steady_gbs()
-        out["roofline_fill"]["steady_frac"] = (out["roofline_fill"]["steady_gbs"] or 0.0) / PEAK_HBM_GBS
-        out["roofline_fill"]["hipmemset_same_bytes_gbs"] = wl2.memset_gbs()
-        wl2.close()
-        trim_pool(local_rank)
-        extras = []
-        for en, ek in ((40000, "battgp"),):
-            if en == n and ek == args.kernel:
-                continue
+        side_errors = {}
+
+        def side(name, fn):
+            """A side measurement never takes the record above down with it."""
+            try:
+                return fn()
+            except Exception as exc:  # noqa: BLE001
+                side_errors[name] = f"{type(exc).__name__}: {exc}"[:300]
+                return None
+
+        def fill_side():
+            # steady rate of the fill kernel and the memset ceiling, beside the in-situ figure
+            wl2 = CellWorkload(n, m, args.kernel, local_rank, n, args)
+            trim_pool(local_rank)
+            try:
+                out["roofline_fill"]["steady_gbs"] = wl2.fill_steady_gbs()
+                out["roofline_fill"]["steady_frac"] = (out["roofline_fill"]["steady_gbs"] or 0.0) / PEAK_HBM_GBS
+                out["roofline_fill"]["hipmemset_same_bytes_gbs"] = wl2.memset_gbs()
+            finally:
+                wl2.close()
+                trim_pool(local_rank)
+
+        def extra_config(en, ek):
             w = CellWorkload(en, m, ek, local_rank, en, args)
-            w.step()
-            ph, t0 = [], time.perf_counter()
-            for _ in range(3):
+            try:
                 w.step()
-                ph.append(w.eng.phase_times())
-            dt = (time.perf_counter() - t0) / 3
-            rec = summarise(ph, en, m, ek, kernel_setup(ek)[2])
-            res = w.eng.residuals(256)
-            rec.update({"ms_per_step": dt * 1e3, "gflops": algorithmic_flop(en, m) / dt / 1e9, "lml": w.eng.lml,
-                        "residuals": {"rel_solve": res[0], "max_llt": res[1]}})
-            extras.append(rec)
-            w.close()
-        out["extra_configs"] = extras
-        out["experiments"] = schedule_experiments()
+                ph, t0 = [], time.perf_counter()
+                for _ in range(3):
+                    w.step()
+                    ph.append(w.eng.phase_times())
+                dt = (time.perf_counter() - t0) / 3
+                rec = summarise(ph, en, m, ek, kernel_setup(ek)[2])
+                res = w.eng.residuals(256)
+                rec.update({"ms_per_step": dt * 1e3, "gflops": algorithmic_flop(en, m) / dt / 1e9, "lml": w.eng.lml,
+                            "residuals": {"rel_solve": res[0], "max_llt": res[1]}})
+                return rec
+            finally:
+                w.close()
+
+        side("fill_steady", fill_side)
+        extras = [side(f"extra_{en}_{ek}", lambda en=en, ek=ek: extra_config(en, ek))
+                  for en, ek in ((40000, "battgp"),) if not (en == n and ek == args.kernel)]
+        out["extra_configs"] = [e for e in extras if e]
+        trim_pool(local_rank)  # the children below need the HBM
+        if not args.no_pmc:
+            live = side("pmc_live", lambda: pmc_live(n, args.kernel, m))
+            out["pmc_live"] = live
+            if live and live.get("hbm_bytes_per_dispatch"):
+                out["roofline"]["traffic"] = live["hbm_bytes_per_dispatch"]
+                out["roofline"]["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload run by this "
+                                                     "bench in child processes (pmc_live); FETCH_SIZE x2 per the gfx950 correction")
+                out["roofline"]["traffic_over_algorithmic_c_traffic"] = live["hbm_bytes_total"] / live["algorithmic_c_traffic_bytes_total"]
+            if live and live.get("mfma_util") is not None:
+                out["roofline"]["mfma_util_pmc"] = live["mfma_util"]
+        out["experiments"] = side("experiments", schedule_experiments)
+        if side_errors:
+            out["side_measurement_errors"] = side_errors
     return out
 
 
@@ -440,6 +557,7 @@ def main() -> None:
     ap.add_argument("--cpu-n", type=int, default=16384, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (steady fill, memset ceiling, N = 40 000 extra config)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes of the headline workload (child processes, ~1-2 min)")
     ap.add_argument("--separate", action="store_true", help="bgp_fit then bgp_predict (separate triangular-solve pass) instead of the fused call")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1: nccl (= RCCL, the driver's runs); gloo with --share-gpu rehearses "
@@ -492,7 +610,10 @@ def main() -> None:
             if sh is not None:
                 out["sharded"] = sh
             if args.cpu_n > 0 and world == 1:
-                out["cpu_baseline"] = cpu_baseline(args.kernel, args.cpu_n, args.m)
+                try:
+                    out["cpu_baseline"] = cpu_baseline(args.kernel, args.cpu_n, args.m)
+                except Exception as exc:  # noqa: BLE001 - the GPU record is printed whatever happens to the host-side sample
+                    out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"[:300]}
             elif world > 1:
                 out["cpu_baseline"] = None
             print(json.dumps(out), flush=True)
