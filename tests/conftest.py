@@ -29,6 +29,20 @@ def pytest_configure(config):
         config._emu.__enter__()
 
 
+# The driver runs the GPU suite with -x: what is most basic (and longest validated on the hardware) goes first, so that a
+# failure in a younger layer (adaptor, sharded driver, optional schedules) can not cut the core parity record short.
+GPU_ORDER = ["test_gpu_parity", "test_gpu_pins_and_sizes", "test_gpu_slab_layout", "test_gpu_adaptor", "test_gpu_sharded",
+             "test_gpu_zz_optional_schedules"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return GPU_ORDER.index(mod) if mod in GPU_ORDER else -1  # CPU modules keep their place in front
+
+    items.sort(key=key)  # stable: the order inside a module is untouched
+
+
 def pytest_unconfigure(config):
     if getattr(config, "_emu", None) is not None:
         config._emu.__exit__(None, None, None)

@@ -12,7 +12,7 @@ import pytest
 from hypothesis import HealthCheck, given, settings
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from problem_gen import check_problem, problems  # noqa: E402
+from problem_gen import LA_MEASURED, check_problem, problems  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -495,43 +495,13 @@ def test_panel_schemes_agree_and_match_oracle(kid, n, nb):
     assert np.max(np.abs(out[1][2] - v_ref) / K.kernel_diag(kid, hyp, xq)) < 1e-9
 
 
-@pytest.mark.parametrize("kid", [K.KERNEL_BATTGP, K.KERNEL_MATERN32])
-@pytest.mark.parametrize("n,nb", [(700, 128), (3001, 512), (20000, 512)])
-def test_slim_chain_kernels_and_split_panels_are_bit_identical(kid, n, nb):
-    """lookahead bit 5: the diagonal-block chain of every panel after the first runs on the kernels sized to fit next
-    to the trailing update's workgroups (potrf_tile_slim, chain_gemm_slim, 32-wide diag_out); bit 6: the panel's solve
-    and look-ahead update are split into the next diagonal block's rows (panel stream) and the tall rest (bulk stream);
-    bit 7: the rank-64 update of a chain step and the tile Cholesky of the next step share one launch.
-    Same arithmetic in the same order for every element, so factor, LML, posterior and tile inverses are identical to
-    the last bit - which at N = 20 000 (a trailing update that really saturates the GPU, four streams in flight) is also
-    the test of the event graph that orders the streams"""
-    hyp = synthetic.HYP_BATTGP if kid == K.KERNEL_BATTGP else synthetic.HYP_MATERN32
-    x, y = synthetic.make_cell_data(n, seed=n + 1)
-    xq = synthetic.make_query(x, 200)
-    out = []
-    for la in (1, 1 | 32, 1 | 64, 1 | 32 | 64, 1 | 128, 1 | 64 | 128):
-        e = ExactGPEngine(kid, hyp)
-        e.set_options(nb_outer=nb, lookahead=la)
-        e.set_panel_scheme(1)
-        lml, m, v = e.fit_predict(x, y, xq, min_var=-1.0)
-        m2, v2 = e.predict(xq[:50], min_var=-1.0)  # later prediction: walks the stored tile / panel inverses
-        diag = e.factor_diag()
-        res = e.residuals(128)
-        e.close()
-        assert res[0] < 1e-6 and res[1] < 1e-11, res
-        out.append((lml, m, v, m2, v2, diag))
-    for o in out[1:]:
-        assert o[0] == out[0][0]
-        for a, b in zip(out[0][1:], o[1:]):
-            assert np.array_equal(a, b)
-
-
 @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
-@given(problems(n_max=3000, m_max=400, noise_lo=-3.0))
+@given(problems(n_max=3000, m_max=400, noise_lo=-3.0, la_words=LA_MEASURED))
 def test_random_problems_match_the_oracle(prob):
     """the property of tests/test_emu_property.py at sizes with dozens of panels: ragged N / M, D = 1..6, all kernels,
-    random hyper-parameters, duplicated points, both panel schemes, every look-ahead word, slab layout - LML, posterior
-    and gradient against the oracle"""
+    random hyper-parameters, duplicated points, both panel schemes, the look-ahead words that have run on the GPU, slab
+    layout - LML, posterior and gradient against the oracle (the optional schedules built while the GPU pool was closed
+    take the same property in tests/test_gpu_zz_optional_schedules.py, in a child process)"""
     check_problem(*prob)
 
 

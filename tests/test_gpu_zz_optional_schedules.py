@@ -1,0 +1,33 @@
+"""The OPTIONAL Cholesky schedules (lookahead bits 5-7) on the GPU - last file of the ``-m gpu`` suite, every case in a
+CHILD process with a time limit.
+
+These kernels were written while the GPU pool was closed to this build: they are off by default, bit-identical to the
+default schedule in the CPU build of the kernel sources, and have never run on the hardware.  Whatever they do there -
+a memory fault, a hang, a differing bit - must fail THIS test only, after every core parity test has already been
+recorded; a fault inside the pytest process itself would take the whole record down."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = os.path.join(HERE, "optional_schedule_cases.py")
+
+
+@pytest.mark.parametrize("case,limit_s", [
+    ("test_slim_chain_kernels_and_split_panels_are_bit_identical", 1200),
+    ("test_random_problems_match_the_oracle_under_the_optional_schedules", 900),
+])
+def test_optional_schedules_in_a_child_process(request, case, limit_s):
+    cmd = [sys.executable, "-m", "pytest", f"{CASES}::{case}", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"]
+    if request.config.getoption("--emu"):
+        cmd.append("--emu")
+    try:
+        r = subprocess.run(cmd, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired as exc:
+        pytest.fail(f"{case}: no result within {limit_s} s (child killed); stdout tail: {(exc.stdout or b'')[-800:]!r}")
+    assert r.returncode == 0, f"{case}: child rc = {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-1500:]}"

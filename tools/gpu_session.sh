@@ -15,7 +15,7 @@ stamp() { echo "[$(date +%H:%M:%S)] $*" | tee -a $OUT/session.log; }
 
 if has tests; then
   stamp "pytest -m gpu"
-  timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest_gpu.log 2>&1
+  timeout 1700 python -m pytest tests -m gpu -q --maxfail=10 --durations=15 > $OUT/pytest_gpu.log 2>&1
   stamp "pytest rc=$? $(tail -1 $OUT/pytest_gpu.log)"
 fi
 if has bench; then
