@@ -267,3 +267,24 @@ def test_system_driver_concurrency_is_a_scheduling_choice_only(monkeypatch):
     state["fail"] = 3
     with pytest.raises(RuntimeError, match="cell 3 failed"):
         run(device=0, in_flight=9)
+
+
+def test_operating_point_record_and_tags():
+    """Op(I, SOC, T): the members the callers use (src/operating_point.py, src/batt_models/cellnr.py) - vector views,
+    the display string that is written to battgpf_info.json, dataclass-like equality / repr, mutability; any object
+    with .I / .SOC / .T compares equal (the reference's own Op can be handed to the plugin)."""
+    from types import SimpleNamespace
+
+    from battgp_amd.operating_point import Op, get_causal_tag, get_cell_tag
+
+    op = Op(-15.0, SOC=90.0, T=25.0)
+    assert op.disp_str() == "I = -15.00 A, SOC = 90.00 %, T = 25.00 °C"
+    assert op.into_array().tolist() == [-15.0, 90.0, 25.0] and op.into_array().dtype == np.float64
+    assert op.into_row_vector().shape == (1, 3)
+    assert repr(op) == "Op(I=-15.0, SOC=90.0, T=25.0)"
+    assert op == Op(-15.0, 90.0, 25.0) and op != Op(-15.0, 90.0, 26.0)
+    assert op == SimpleNamespace(I=-15.0, SOC=90.0, T=25.0) and op != "x"
+    op.T = 30.0
+    assert op.into_array()[2] == 30.0
+    assert [get_cell_tag(c) for c in (-1, 0, 12)] == ["pack", "c0", "c12"]
+    assert (get_causal_tag(True), get_causal_tag(False)) == ("causal", "acausal")
