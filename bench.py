@@ -465,7 +465,7 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
 
         side("fill_steady", fill_side)
         extras = [side(f"extra_{en}_{ek}", lambda en=en, ek=ek: extra_config(en, ek))
-                  for en, ek in ((40000, "battgp"),) if not (en == n and ek == args.kernel)]
+                  for en, ek in ((args.extra_n, "battgp"),) if en > 0 and not (en == n and ek == args.kernel)]
         out["extra_configs"] = [e for e in extras if e]
         trim_pool(local_rank)  # the children below need the HBM
         if not args.no_pmc:
@@ -557,6 +557,7 @@ def main() -> None:
     ap.add_argument("--cpu-n", type=int, default=16384, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (steady fill, memset ceiling, N = 40 000 extra config)")
+    ap.add_argument("--extra-n", type=int, default=40000, help="size of the extra configuration measured beside the headline (BASELINE configs[1]: 40 000, the reference kernel; 0 = skip)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes of the headline workload (child processes, ~1-2 min)")
     ap.add_argument("--separate", action="store_true", help="bgp_fit then bgp_predict (separate triangular-solve pass) instead of the fused call")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -80,3 +80,72 @@ def test_pmc_live_reports_a_missing_or_failing_profiler(tmp_path, monkeypatch):
     out = bench.pmc_live(2048, "battgp", limit_s=30)
     assert all(p["rc"] == 7 for p in out["passes"].values())
     assert "hbm_bytes_per_dispatch" not in out and "mfma_util" not in out
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_the_drivers_multi_gpu_launch_of_bench_py_rehearsed_on_the_cpu_build():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 --steps K --warmup W` - the launch the
+    driver uses for SCALE, which no GPU has executed yet - with the CPU build of the kernel sources behind the binding
+    (tests/emu/run_bench_emu.py) and gloo between the ranks: rendezvous, barriers, max-over-ranks timing, one cell per
+    rank, the appended `sharded` sub-record (ONE GP over both ranks) and the single JSON line of rank 0.  The numbers it
+    prints are not measurements; the LML values in it are checked against the oracle."""
+    import subprocess
+
+    from battgp_amd import KERNEL_MATERN32, synthetic
+    from oracle.exact_gp import OracleGP
+
+    n, ns = 600, 384
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "emu", "run_bench_emu.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", str(n), "--backend", "gloo", "--share-gpu",
+           "--sharded-n", str(ns), "--sharded-nb", "128"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["unit"] == "GFLOP/s" and out["dtype"] == "f64" and out["vs_baseline"] is None and out["cpu_baseline"] is None
+    assert out["config"]["parallelism"] == "2 independent cells" and "workload" in out["config"]
+    # whole-job value: both cells' flop over the slowest rank's time
+    assert out["value"] == pytest.approx(2 * out["config"]["flop_per_step"] / (out["ms_per_step"] * 1e-3) / 1e9, rel=1e-9)
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+    x, y = synthetic.make_cell_data(n, seed=n)  # rank 0's cell
+    assert out["lml"] == pytest.approx(OracleGP(KERNEL_MATERN32, synthetic.HYP_MATERN32, x, y).fit().lml, rel=1e-9)
+    sh = out["sharded"]
+    assert sh["world"] == 2 and sh["n"] == ns and sh["scaling"] == "strong"
+    xs, ys = synthetic.make_cell_data(ns)
+    assert sh["lml"] == pytest.approx(OracleGP(KERNEL_MATERN32, synthetic.HYP_MATERN32, xs, ys).fit().lml, rel=1e-9)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_side_measurements_cannot_take_the_bench_record_down(tmp_path):
+    """the default single-GPU invocation rehearsed on the CPU build, where several side measurements MUST fail (no
+    device for torch's memset timing, no profiler, no GPU for the A/B child): the record of the timed steps is printed
+    all the same, with what did run (steady fill, the extra configuration) and the failures listed"""
+    import subprocess
+
+    env = dict(os.environ, BGP_ROCPROFV3=str(tmp_path / "absent"))
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_bench_emu.py"), "--steps", "1", "--warmup", "0", "--size", "600",
+           "--extra-n", "500", "--cpu-n", "300"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["n"] == 600 and out["lml"] == out["lml"]
+    assert out["roofline_fill"]["steady_gbs"] > 0                      # ran
+    assert "fill_steady" in out["side_measurement_errors"]             # torch's event timing has no device here
+    assert out["pmc_live"] == {"rc": "rocprofv3 not found"} and out["roofline"]["traffic"] is None
+    assert out["experiments"]["rc"] != 0 and out["experiments"]["runs"] == []
+    assert [e["workload"].split(", N=")[1].split(" ")[0] for e in out["extra_configs"]] == ["500"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["phases"]) == {"fill_s", "potrf_s", "solve_predict_s"}
