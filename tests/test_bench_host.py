@@ -149,3 +149,16 @@ def test_side_measurements_cannot_take_the_bench_record_down(tmp_path):
     assert [e["workload"].split(", N=")[1].split(" ")[0] for e in out["extra_configs"]] == ["500"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["phases"]) == {"fill_s", "potrf_s", "solve_predict_s"}
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_smoke_entry_point_rehearsed_on_the_cpu_build():
+    """__graft_entry__.smoke() - what the driver runs first on the GPU box - through the CPU build of the kernel
+    sources: engine call, oracle comparison and the plugin surface on top, end to end"""
+    import subprocess
+
+    code = ("import sys; sys.path.insert(0, 'tests/emu'); from inject import fake_cuda_tensors, installed; fake_cuda_tensors()\n"
+            "import __graft_entry__ as g\n"
+            "with installed():\n    g.smoke()\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
