@@ -96,7 +96,7 @@ def _free_port():
 def test_the_drivers_multi_gpu_launch_of_bench_py_rehearsed_on_the_cpu_build():
     """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 --steps K --warmup W` - the launch the
     driver uses for SCALE, which no GPU has executed yet - with the CPU build of the kernel sources behind the binding
-    (tests/emu/run_bench_emu.py) and gloo between the ranks: rendezvous, barriers, max-over-ranks timing, one cell per
+    (tests/emu/run_script_emu.py) and gloo between the ranks: rendezvous, barriers, max-over-ranks timing, one cell per
     rank, the appended `sharded` sub-record (ONE GP over both ranks) and the single JSON line of rank 0.  The numbers it
     prints are not measurements; the LML values in it are checked against the oracle."""
     import subprocess
@@ -106,7 +106,7 @@ def test_the_drivers_multi_gpu_launch_of_bench_py_rehearsed_on_the_cpu_build():
 
     n, ns = 600, 384
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "emu", "run_bench_emu.py"),
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py",
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", str(n), "--backend", "gloo", "--share-gpu",
            "--sharded-n", str(ns), "--sharded-nb", "128"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -136,7 +136,7 @@ def test_side_measurements_cannot_take_the_bench_record_down(tmp_path):
     import subprocess
 
     env = dict(os.environ, BGP_ROCPROFV3=str(tmp_path / "absent"))
-    cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_bench_emu.py"), "--steps", "1", "--warmup", "0", "--size", "600",
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py", "--steps", "1", "--warmup", "0", "--size", "600",
            "--extra-n", "500", "--cpu-n", "300"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -162,3 +162,28 @@ def test_smoke_entry_point_rehearsed_on_the_cpu_build():
             "with installed():\n    g.smoke()\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+@pytest.mark.parametrize("argv,expect", [
+    (["tools/sweep_n.py", "1", "300"], '"fit_predict_ms"'),
+    (["tools/system_probe.py", "300"], '"predict_all_ms"'),
+    (["tools/train_iter.py", "300"], '"refit_plus_grad_ms"'),
+    (["tools/fill_rate.py", "1024"], "median"),
+    (["tools/profile_workload.py", "700", "matern32"], '"alpha_norm"'),
+    (["tools/ab_lookahead.py", "1", "700"], '"identical_to_default": true'),
+    (["tools/large_n.py", "1500"], '"fit_predict_s"'),
+    (["bench.py", "--mode", "sharded", "--size", "700", "--kernel", "battgp", "--steps", "1", "--warmup", "1", "--cpu-n", "0",
+      "--no-extras", "--backend", "gloo", "--force-group", "--sharded-nb", "128"], '"scaling": "strong"'),
+])
+def test_gpu_session_scripts_rehearsed_on_the_cpu_build(argv, expect):
+    """every script tools/gpu_session.sh spends GPU minutes on runs to completion on the CPU build of the kernel sources
+    (control flow and output format only - a Python error must not be what the first GPU minutes find)"""
+    import subprocess
+
+    env = dict(os.environ, BGP_ONLY="battgp")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), *argv], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and expect in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    if argv[0] == "tools/ab_lookahead.py":
+        assert '"identical_to_default": false' not in r.stdout
