@@ -426,8 +426,17 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
 
         side_errors = {}
 
-        def side(name, fn):
-            """A side measurement never takes the record above down with it."""
+        t_side0 = time.perf_counter()
+
+        def remaining():
+            return args.side_budget_s - (time.perf_counter() - t_side0)
+
+        def side(name, fn, need_s=0.0):
+            """A side measurement never takes the record above down with it, and none is started once the time budget
+            for all of them (--side-budget-s) can no longer cover it."""
+            if remaining() < need_s:
+                side_errors[name] = f"skipped: {remaining():.0f} s of the side budget left, needs ~{need_s:.0f} s"
+                return None
             try:
                 return fn()
             except Exception as exc:  # noqa: BLE001
@@ -463,13 +472,15 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
             finally:
                 w.close()
 
-        side("fill_steady", fill_side)
-        extras = [side(f"extra_{en}_{ek}", lambda en=en, ek=ek: extra_config(en, ek))
+        side("fill_steady", fill_side, 20.0)
+        extras = [side(f"extra_{en}_{ek}", lambda en=en, ek=ek: extra_config(en, ek), 10.0)
                   for en, ek in ((args.extra_n, "battgp"),) if en > 0 and not (en == n and ek == args.kernel)]
         out["extra_configs"] = [e for e in extras if e]
         trim_pool(local_rank)  # the children below need the HBM
         if not args.no_pmc:
-            live = side("pmc_live", lambda: pmc_live(n, args.kernel, m))
+            # three passes of one fit+predict each (+ process start): the step time is the best estimate of a pass
+            pass_s = 3.0 * (elapsed / args.steps) + 30.0
+            live = side("pmc_live", lambda: pmc_live(n, args.kernel, m, limit_s=max(60.0, min(240.0, remaining() / 3.0))), 3.0 * pass_s)
             out["pmc_live"] = live
             if live and live.get("hbm_bytes_per_dispatch"):
                 out["roofline"]["traffic"] = live["hbm_bytes_per_dispatch"]
@@ -478,7 +489,7 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
                 out["roofline"]["traffic_over_algorithmic_c_traffic"] = live["hbm_bytes_total"] / live["algorithmic_c_traffic_bytes_total"]
             if live and live.get("mfma_util") is not None:
                 out["roofline"]["mfma_util_pmc"] = live["mfma_util"]
-        out["experiments"] = side("experiments", schedule_experiments)
+        out["experiments"] = side("experiments", lambda: schedule_experiments(max(30.0, min(150.0, remaining()))), 30.0)
         if side_errors:
             out["side_measurement_errors"] = side_errors
     return out
@@ -557,6 +568,9 @@ def main() -> None:
     ap.add_argument("--cpu-n", type=int, default=16384, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (steady fill, memset ceiling, N = 40 000 extra config)")
+    ap.add_argument("--side-budget-s", type=float, default=480.0,
+                    help="time budget of ALL side measurements after the timed region (steady fill, extra configuration, PMC passes, "
+                         "schedule A/B); one that no longer fits is skipped and listed under side_measurement_errors")
     ap.add_argument("--extra-n", type=int, default=40000, help="size of the extra configuration measured beside the headline (BASELINE configs[1]: 40 000, the reference kernel; 0 = skip)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes of the headline workload (child processes, ~1-2 min)")
     ap.add_argument("--separate", action="store_true", help="bgp_fit then bgp_predict (separate triangular-solve pass) instead of the fused call")

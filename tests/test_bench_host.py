@@ -187,3 +187,19 @@ def test_gpu_session_scripts_rehearsed_on_the_cpu_build(argv, expect):
     assert r.returncode == 0 and expect in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     if argv[0] == "tools/ab_lookahead.py":
         assert '"identical_to_default": false' not in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_side_measurements_respect_their_time_budget():
+    """--side-budget-s: a side measurement that no longer fits is not started and is listed as skipped"""
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py", "--steps", "1", "--warmup", "0",
+           "--size", "400", "--extra-n", "300", "--cpu-n", "0", "--side-budget-s", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    errs = out["side_measurement_errors"]
+    assert set(errs) == {"fill_steady", "extra_300_battgp", "pmc_live", "experiments"} and all(v.startswith("skipped") for v in errs.values())
+    assert out["extra_configs"] == [] and out["pmc_live"] is None and out["experiments"] is None
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
