@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE ONLY: one pass over the engine's code paths through the AddressSanitizer build of the CPU
 stand-in (tests/emu).  Run by tests/test_emu_kernels.py::test_address_sanitizer_pass in a child process that has the
 sanitizer runtime preloaded; every global / LDS / workspace access of the UNMODIFIED kernel sources is bounds-checked
-(device buffers are plain heap allocations there, LDS arrays are stack/static arrays of the block)."""
+(device buffers are plain heap allocations there, LDS arrays are stack/static arrays of the block).  Covers the single-GPU engine
+(fit, fused and later predictions, gradient, slab layout, optional schedules) and the sharded driver's building blocks."""
 
 import os
 import sys
@@ -44,6 +45,20 @@ def main() -> int:
                 assert r[0] < 1e-6
                 e.refit(hyp)
                 e.close()
+        # the sharded driver's per-panel building blocks (fill block, factor + pack, panel updates, panel solve, row
+        # dots) on one rank: ragged sizes, several panels, a single short panel
+        from inject import fake_cuda_tensors
+
+        fake_cuda_tensors()  # this child process only: the driver's torch "device" buffers are host memory here
+        from battgp_amd.sharded import make_sharded_gp
+
+        for kid, hyp, n, nb in ((0, synthetic.HYP_BATTGP, 333, 128), (2, synthetic.HYP_MATERN32, 61, 64)):
+            x, y = synthetic.make_cell_data(n, seed=3)
+            gp = make_sharded_gp(kid, hyp, nb=nb, backend_name="gloo", local_rank=0)
+            lml = gp.fit(x, y)
+            mean, var = gp.predict(synthetic.make_query(x, 37))
+            assert np.isfinite(lml) and np.all(np.isfinite(mean)) and np.all(var > 0)
+            gp.close()
     print("ASAN-PASS-DONE")
     return 0
 

@@ -1,7 +1,10 @@
 """TEST INFRASTRUCTURE ONLY: a longer, randomly seeded run of the property behind tests/test_emu_property.py (random ragged
 exact-GP problems through the whole C-ABI path on the CPU build of the kernel sources, against the oracle) - the CPU
 suite runs 150 derandomised examples, this runs as many as asked for with fresh seeds and prints the first
-counter-example.       python tests/emu/fuzz_campaign.py [examples] [n_max] [seed]"""
+counter-example.       python tests/emu/fuzz_campaign.py [examples] [n_max] [seed]
+With FUZZ_ASAN=1 (and the sanitizer runtime preloaded: LD_PRELOAD=$(python -c "import build_emu; print(build_emu.sanitizer_runtime('asan'))")
+ASAN_OPTIONS=detect_leaks=0) the campaign runs through the AddressSanitizer build: every access of the random ragged
+shapes is bounds-checked."""
 import os
 import sys
 
@@ -28,7 +31,7 @@ def campaign(prob):
     check_problem(*prob)
 
 
-with installed():
+with installed(sanitize="asan" if os.environ.get("FUZZ_ASAN") else False):
     print(f"seed {rseed}, {examples} examples, n_max {n_max}", flush=True)
     campaign()
     print(f"ok: {count[0]} problems agree with the oracle", flush=True)
