@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbattgp.so")
 SOURCES = ["bgp_fill.hip", "bgp_linalg.hip", "bgp_capi.hip"]
-HEADERS = [os.path.join(CSRC, "bgp_internal.h"), os.path.join(os.path.dirname(HERE), "include", "battgp.h")]
+HEADERS = [os.path.join(CSRC, "bgp_internal.h"), os.path.join(CSRC, "bgp_fill_tile.inc"), os.path.join(os.path.dirname(HERE), "include", "battgp.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

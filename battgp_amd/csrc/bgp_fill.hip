@@ -249,6 +249,127 @@ __device__ __forceinline__ double kfun_interior(const double (&a)[DD], const dou
 
 __device__ __forceinline__ bool not_finite(double v) { return !(__builtin_fabs(v) <= 1.7976931348623157e308); }
 
+typedef double fill_v4d __attribute__((ext_vector_type(4)));
+
+// Interior tile with the squared distances on the MATRIX pipe (ABL bit 3, BGP_FILL_MFMA=1; written without a GPU at
+// hand: NOT timed, off by default).  The fill is bound by its VALU instruction count at the clock the SMU grants it
+// (see below); 6 of the ~29 instructions per entry form q_ij = sum_d (a_id - b_jd)^2.  Expanded around a common shift c
+// (the mid-range of the tile's 32 column points, so that |a - c|, |b - c| stay small and the cancellation harmless),
+//     q_ij = |b'_j|^2 + sum_d (-2 b'_jd) a'_id + sum_d 1 * a'_id^2,        a' = a - c,  b' = b - c,
+// is two v_mfma_f64_16x16x4_f64 per 16 x 16 entries - first operand (-2 b'_j | 1), second operand (a'_i | a'_i^2), the
+// accumulator starting as |b'_j|^2 - on a pipe the kernel does not otherwise use: 64 cycles per 256 entries against
+// the 24 VALU cycles per entry the subtractions and FMAs cost.  A wave owns 128 rows x 32 columns of the tile; lane
+// (l15, l4) supplies ONE coordinate (dimension l4) of its points and receives, per MFMA, the entries
+// (row(b, l15), column a 16 + l4 + 4 r), r = 0..3; rows are dealt so that the blocks 2c and 2c + 1 of a lane are
+// adjacent rows: stores stay 16 B per lane, 256 B contiguous per column.
+// Rounding: |error(q)| <~ 4 eps (|a'|^2 + |b'|^2); tiles with |a'|^2 or |b'|^2 above FILL_MFMA_LIMIT take the VALU path
+// (return false), so the entry's relative error stays below ~1e-13 (d g / g = dq / (2 (1 + r)) for Matern-3/2, dq for
+// the squared-exponential kernels) - inside the 2e-13 elementwise parity bound, an order of magnitude above the VALU path.
+constexpr double FILL_MFMA_LIMIT = 96.0;
+
+template <int KID, bool T256>
+__device__ __forceinline__ bool fill_interior_mfma(const FillParams& p, const double* __restrict__ x1, int64_t i0, int64_t j0,
+                                                   double* __restrict__ out, int64_t ld, const double (*sB)[4],
+                                                   const double (*sW)[2], double* __restrict__ sShift,
+                                                   double* __restrict__ sNb, const double* __restrict__ sTs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  constexpr int D0 = (KID == BGP_KERNEL_BATTGP) ? 1 : 0;  // K0: the time column is not part of the RBF distance
+  if (tid < 4) {  // mid-range of the 32 column points, per dimension (scaled coordinates)
+    double lo = sB[0][tid], hi = lo;
+    for (int c = 1; c < FT_COLS; ++c) {
+      lo = __builtin_fmin(lo, sB[c][tid]);
+      hi = __builtin_fmax(hi, sB[c][tid]);
+    }
+    sShift[tid] = 0.5 * (lo + hi);
+  }
+  __syncthreads();
+  int big = 0;
+  if (tid < FT_COLS) {
+    double nb = 0.0;
+#pragma unroll
+    for (int d = D0; d < 4; ++d) {
+      const double b = sB[tid][d] - sShift[d];
+      nb = __builtin_fma(b, b, nb);
+    }
+    sNb[tid] = nb;
+    big |= !(nb <= FILL_MFMA_LIMIT);
+  }
+  // this lane's coordinate (dimension l4) of its 8 row points: block b, lane l15 -> row (b >> 1) 32 + 2 l15 + (b & 1)
+  const bool used = l4 >= D0;
+  const double shift = sShift[l4], scale = p.scale[l4];
+  const int64_t irow = i0 + wave * 128 + 2 * l15;
+  double ya[8], yq[8], tr[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int64_t i = irow + (b >> 1) * 32 + (b & 1);
+    const double v = x1[i * 4 + l4];
+    const double a = used ? __builtin_fma(v, scale, -shift) : 0.0;
+    ya[b] = a;
+    yq[b] = a * a;
+    if (KID == BGP_KERNEL_BATTGP) tr[b] = x1[i * 4];  // t_i of the sorted-time Wiener term
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    // |a'|^2 of row (b, l15): the four lanes l15, l15 + 16, + 32, + 48 hold its components.  Lanes 0..15 end up with the
+    // full sum, the others with partial sums (<= the full one: no false alarms)
+    double n2 = yq[b];
+    n2 += __shfl_down(n2, 32);
+    n2 += __shfl_down(n2, 16);
+    big |= !(n2 <= FILL_MFMA_LIMIT);
+  }
+  if (__syncthreads_or(big)) return false;
+
+  double xa[2];
+  fill_v4d nbv[2];
+  double w0[2][4], w1[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    xa[a] = used ? -2.0 * (sB[a * 16 + l15][l4] - shift) : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = a * 16 + l4 + 4 * r;
+      nbv[a][r] = sNb[c];
+      if (KID == BGP_KERNEL_BATTGP) {
+        w0[a][r] = sW[c][0];
+        w1[a][r] = sW[c][1];
+      }
+    }
+  }
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  auto entry = [&](double q, int a, int r, int b) -> double {
+    if (KID == BGP_KERNEL_BATTGP) {
+      const double e = T256 ? exp_interior(-q, sTs) : exp_nonpos_t<true>(-q, sTs);  // s_r e^-q
+      return __builtin_fma(w0[a][r], tr[b], w1[a][r]) + e;
+    } else if (KID == BGP_KERNEL_MATERN32) {
+      q = __builtin_fmax(q, 1e-300);  // cancellation may leave a tiny negative number at coincident points
+      const double y = __builtin_amdgcn_rsq(q);
+      double rr = q * y;
+      rr = __builtin_fma(__builtin_fma(-rr, rr, q), 0.5 * y, rr);
+      const double se = T256 ? exp_interior(-rr, sTs) : exp_nonpos_t<true>(-rr, sTs);
+      return __builtin_fma(rr, se, se);
+    } else {
+      return T256 ? exp_interior(-q, sTs) : exp_nonpos_t<true>(-q, sTs);
+    }
+  };
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      fill_v4d q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a], ya[2 * c], nbv[a], 0, 0, 0);
+      fill_v4d q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a], ya[2 * c + 1], nbv[a], 0, 0, 0);
+      q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, yq[2 * c], q0, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, yq[2 * c + 1], q1, 0, 0, 0);
+      double* dst = out + (irow + c * 32) + (j0 + a * 16 + l4) * ld;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v2d vv = {entry(q0[r], a, r, 2 * c), entry(q1[r], a, r, 2 * c + 1)};
+        __builtin_nontemporal_store(vv, reinterpret_cast<v2d*>(dst + (int64_t)(4 * r) * ld));
+      }
+    }
+  }
+  return true;
+}
+
 // ABL != 0: ablation variants for tools/fill_ablate.hip only (1 = no kernel math, 2 = no stores)
 // UNR: unroll of the interior column loop.  Interior tiles store non-temporally: the matrix is written once and
 // next read by another kernel after > 100 GB of other traffic (+5-6 % on the store stream, tools/fill_gap_probe.py).
@@ -262,130 +383,21 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
                                                    int64_t n2, double* __restrict__ out, int64_t ld,
                                                    int lower, int add_diag, int64_t nv1, int64_t nv2,
                                                    int nti, int ntj, int vec_ok) {
-  constexpr int DD = DT ? DT : BGP_MAX_DIM;
-  const int D = DT ? DT : p.D;
-  __shared__ double sB[FT_COLS][DD];
-  __shared__ double sW[FT_COLS][2];  // K0: A_j = s_w t_j^2 / 2, B_j = -s_w t_j^3 / 6
-  constexpr bool T256 = (ABL & 4) != 0;  // ABL bit 2: the 256-entry interior table (BGP_FILL_TABLE=256, not yet timed)
-  __shared__ double sT[64];          // 2^(i/64) ...
-  __shared__ double sTs[T256 ? 256 : 64];  // ... and the same (or 2^(i/256)) times the output scale (s_r for K0, s otherwise)
-  const double oscale = (KID == BGP_KERNEL_BATTGP) ? p.s1 : p.s0;
-  if (T256) {
-    // 2^(1/256), 2^(2/256), 2^(3/256) correctly rounded; 2^(i/256) = 2^((i >> 2)/64) 2^((i & 3)/256) to ~1 ulp
-    const double fine[4] = {1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175};
-    if (threadIdx.x < 64) sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
-    sTs[threadIdx.x % (T256 ? 256 : 64)] = (EXP2_TBL[threadIdx.x >> 2] * fine[threadIdx.x & 3]) * oscale;
-  } else if (threadIdx.x < 64) {
-    sT[threadIdx.x] = EXP2_TBL[threadIdx.x];
-    sTs[threadIdx.x] = EXP2_TBL[threadIdx.x] * oscale;
-  }
+#include "bgp_fill_tile.inc"
+}
 
-  int ti, tj;
-  if (lower) {
-    if (!lower_decode((int64_t)blockIdx.x, nti, ntj, ti, tj)) return;
-  } else {
-    ti = (int)(blockIdx.x % (unsigned)nti);
-    tj = (int)(blockIdx.x / (unsigned)nti);
-  }
-  const int64_t i0 = (int64_t)ti * FT_ROWS, j0 = (int64_t)tj * FT_COLS;
-
-  int bad = 0;  // a NaN / inf coordinate anywhere in the tile sends it down the general path
-  for (int idx = threadIdx.x; idx < FT_COLS * DD; idx += 256) {
-    int c = idx / DD, d = idx % DD;
-    int64_t j = j0 + c;
-    double v = 0.0;
-    if (j < nv2 && d < D) {
-      v = x2[j * D + d];
-      bad |= not_finite(v) ? 1 : 0;
-      if (KID == BGP_KERNEL_BATTGP && d == 0) {
-        sW[c][0] = (0.5 * p.s0) * v * v;
-        sW[c][1] = (-p.s0 / 6.0) * v * v * v;
-      } else {
-        v *= p.scale[d];
-      }
-    }
-    sB[c][d] = v;
-  }
-
-  const int64_t i = i0 + 2 * (int64_t)threadIdx.x;
-  double a0[DD], a1[DD];
-  load_point<KID, DD>(x1, i, nv1, D, p, a0);
-  load_point<KID, DD>(x1, i + 1, nv1, D, p, a1);
-#pragma unroll
-  for (int d = 0; d < DD; ++d) bad |= (not_finite(a0[d]) || not_finite(a1[d])) ? 1 : 0;
-  bad = __syncthreads_or(bad);
-
-  const double s0 = p.s0, s1 = p.s1, noise = p.noise;
-
-  // Fast path for the vast majority of tiles: completely inside the valid region and off the
-  // diagonal => no predicates, no padding logic, one branch-free basic block of 32 column steps.
-  const bool touches_diag = add_diag && (j0 < i0 + FT_ROWS) && (i0 < j0 + FT_COLS);
-  const bool interior = vec_ok && !touches_diag && !bad && (i0 + FT_ROWS <= nv1) && (i0 + FT_ROWS <= n1) &&
-                        (j0 + FT_COLS <= nv2) && (j0 + FT_COLS <= n2);
-  if (interior) {
-    double* dst = out + i + j0 * ld;
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    auto columns = [&](auto sorted_tag) {
-      constexpr bool SORTED = decltype(sorted_tag)::value;
-#pragma unroll UNR
-      for (int c = 0; c < FT_COLS; ++c) {
-        double b[DD], w[2] = {0.0, 0.0};
-#pragma unroll
-        for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
-        if (SORTED) {
-          w[0] = sW[c][0];
-          w[1] = sW[c][1];
-        }
-        double v0 = (ABL & 1) ? a0[1] + b[1] : kfun_interior<KID, DD, SORTED, T256>(a0, b, w, D, s0, sTs);
-        double v1 = (ABL & 1) ? a1[1] - b[1] : kfun_interior<KID, DD, SORTED, T256>(a1, b, w, D, s0, sTs);
-        if (ABL & 2) {
-          if (v0 + v1 == 1.2345e300) out[0] = v0;
-        } else {
-          v2d vv = {v0, v1};
-          __builtin_nontemporal_store(vv, reinterpret_cast<v2d*>(dst + (int64_t)c * ld));
-        }
-      }
-    };
-    // strictly below the diagonal of a matrix with ascending times (x1 == x2 there): min(t_i, t_j) = t_j
-    if (KID == BGP_KERNEL_BATTGP && p.t_sorted && lower && i0 >= j0 + FT_COLS) columns(std::true_type{});
-    else columns(std::false_type{});
-    return;
-  }
-
-  const bool r0_in = i < n1, r1_in = i + 1 < n1;
-  const bool r0_val = i < nv1, r1_val = i + 1 < nv1;
-#pragma unroll 4
-  for (int c = 0; c < FT_COLS; ++c) {
-    const int64_t j = j0 + c;
-    if (j >= n2) break;
-    double b[DD];
-#pragma unroll
-    for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
-    double v0 = (ABL & 1) ? a0[1] + b[1] : kfun<KID, DD>(a0, b, D, s0, s1, sT);
-    double v1 = (ABL & 1) ? a1[1] - b[1] : kfun<KID, DD>(a1, b, D, s0, s1, sT);
-    const bool cval = j < nv2;
-    if (ABL & 2) {  // keep the math alive without the store stream
-      if (v0 + v1 == 1.2345e300) out[0] = v0;
-      continue;
-    }
-    if (add_diag) {
-      // training fill: + noise on the diagonal; padding rows/cols form an identity block
-      if (!(cval && r0_val)) v0 = (i == j) ? 1.0 : 0.0;
-      else if (i == j) v0 += noise;
-      if (!(cval && r1_val)) v1 = (i + 1 == j) ? 1.0 : 0.0;
-      else if (i + 1 == j) v1 += noise;
-    } else {
-      if (!(cval && r0_val)) v0 = 0.0;
-      if (!(cval && r1_val)) v1 = 0.0;
-    }
-    double* dst = out + i + j * ld;
-    if (vec_ok && r1_in) {
-      *reinterpret_cast<double2*>(dst) = make_double2(v0, v1);
-    } else {
-      if (r0_in) dst[0] = v0;
-      if (r1_in) dst[1] = v1;
-    }
-  }
+// the matrix-pipe variant (fill_interior_mfma): two workgroups per CU by contract, so that the register budget is 256
+// and the MFMA results land in ordinary VGPRs (with the default budget of 512 the compiler parks them in AGPRs and pays
+// two v_accvgpr_read per entry - the instructions the variant exists to save)
+template <int KID, int ABL, int UNR>
+__global__ __launch_bounds__(256, 2) void fill_mfma_kernel(FillParams p, const double* __restrict__ x1,
+                                                           int64_t n1, const double* __restrict__ x2,
+                                                           int64_t n2, double* __restrict__ out, int64_t ld,
+                                                           int lower, int add_diag, int64_t nv1, int64_t nv2,
+                                                           int nti, int ntj, int vec_ok) {
+  static_assert((ABL & 8) != 0, "the matrix-pipe variant");
+  constexpr int DT = 4;
+#include "bgp_fill_tile.inc"
 }
 
 template <int KID>
@@ -405,7 +417,14 @@ int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t
   // measured at N = 131 072 (steady GB/s by unroll 2 / 4 / 8 / 16): K0 5810 / 5750 / 5640 / 5780, Matern 5440 / 5570 / 5440 / 5470
   constexpr int UNR_DEFAULT = (KID == BGP_KERNEL_BATTGP) ? 2 : 4;
   static const bool t256 = getenv("BGP_FILL_TABLE") && atoi(getenv("BGP_FILL_TABLE")) == 256;  // experiment knob (A/B pending)
-  if (p.D == 4 && t256)
+  static const bool fmfma = getenv("BGP_FILL_MFMA") && atoi(getenv("BGP_FILL_MFMA")) == 1;  // experiment knob (A/B pending)
+  if (p.D == 4 && fmfma && t256)
+    hipLaunchKernelGGL((fill_mfma_kernel<KID, 12, UNR_DEFAULT>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag,
+                       nv1, nv2, nti, ntj, vec_ok);
+  else if (p.D == 4 && fmfma)
+    hipLaunchKernelGGL((fill_mfma_kernel<KID, 8, UNR_DEFAULT>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag,
+                       nv1, nv2, nti, ntj, vec_ok);
+  else if (p.D == 4 && t256)
     hipLaunchKernelGGL((fill_kernel<KID, 4, 4, UNR_DEFAULT>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag,
                        nv1, nv2, nti, ntj, vec_ok);
   else if (p.D == 4 && unr == 2) FILL_UNR(2);

@@ -8,6 +8,7 @@ import os
 import sys
 
 os.environ["BGP_FILL_TABLE"] = "256"  # this process also takes the optional 256-entry interior table of the fill
+os.environ["BGP_FILL_MFMA"] = "1"     # ... and the matrix-pipe form of the interior tiles' squared distances
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
@@ -45,6 +46,15 @@ def main() -> int:
                 assert r[0] < 1e-6
                 e.refit(hyp)
                 e.close()
+        # interior tiles of the fill (512 x 32, off the diagonal): cross fills with two full row tiles and a ragged third -
+        # the optional interior paths set above (the sorted-time K0 form below the diagonal of a training fill is covered,
+        # without the sanitizer, by tests/test_emu_kernels.py::test_optional_interior_paths_of_the_fill)
+        xs, ys = synthetic.make_cell_data(1100, seed=11)
+        for kid, hyp in ((2, synthetic.HYP_MATERN32), (3, np.array([2.33e-6, 0.0099, 400.0, 12.11, 33.75, 45.14]))):
+            e = ExactGPEngine(kid, hyp)
+            km = e.kernel_matrix(synthetic.make_cell_data(64, seed=12)[0], xs)
+            assert km.shape == (64, 1100) and np.all(np.isfinite(km))
+            e.close()
         # the sharded driver's per-panel building blocks (fill block, factor + pack, panel updates, panel solve, row
         # dots) on one rank: ragged sizes, several panels, a single short panel
         from inject import fake_cuda_tensors

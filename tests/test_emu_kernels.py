@@ -285,3 +285,33 @@ def test_sharded_device_backend_ranks_on_the_cpu_build(world, sched):
         assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
         assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
     assert all(r[1:] == res[0][1:] for r in res)
+
+
+def test_optional_interior_paths_of_the_fill():
+    """BGP_FILL_MFMA=1 (squared distances of the interior tiles on the matrix pipe: two v_mfma_f64_16x16x4 per 16 x 16
+    entries, expanded around the mid-range of the tile's column points) and BGP_FILL_TABLE=256, alone and together,
+    against the oracle's kernel code: elementwise relative error of a cross fill with interior tiles below the 2e-13
+    parity bound (measured ~1e-14), LML of a training fit with interior tiles below the diagonal at 1e-9, and bits that
+    DIFFER from the default path's (the knobs are read once per process: child processes; differing bits prove that
+    the optional path was taken and did not fall back)."""
+    import json
+    import subprocess
+
+    script = os.path.join(HERE, "emu", "fill_variant_check.py")
+    envs = {"default": {}, "mfma": {"BGP_FILL_MFMA": "1"}, "mfma+t256": {"BGP_FILL_MFMA": "1", "BGP_FILL_TABLE": "256"}}
+    procs = {k: subprocess.Popen([sys.executable, script], env=dict(os.environ, **e), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k, e in envs.items()}
+    res = {}
+    for k, pr in procs.items():
+        so, se = pr.communicate(timeout=900)
+        assert pr.returncode == 0, se[-2000:]
+        res[k] = json.loads(so.strip().splitlines()[-1])
+    for k, r in res.items():
+        for kid, v in r.items():
+            assert v["cross_max_rel"] < 2e-13, (k, kid, v)
+            assert v["lml_rel"] < 1e-9, (k, kid, v)
+    for k in ("mfma", "mfma+t256"):
+        for kid in res[k]:
+            if kid != "0":  # K0 takes it only where the sorted-time Wiener form applies: below the diagonal of a training fill
+                assert res[k][kid]["digest"] != res["default"][kid]["digest"], (k, kid)            # cross fill took the path
+            assert res[k][kid]["factor_digest"] != res["default"][kid]["factor_digest"], (k, kid)  # and so did the training fill

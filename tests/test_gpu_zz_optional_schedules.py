@@ -31,3 +31,28 @@ def test_optional_schedules_in_a_child_process(request, case, limit_s):
     except subprocess.TimeoutExpired as exc:
         pytest.fail(f"{case}: no result within {limit_s} s (child killed); stdout tail: {(exc.stdout or b'')[-800:]!r}")
     assert r.returncode == 0, f"{case}: child rc = {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-1500:]}"
+
+
+def test_optional_interior_paths_of_the_fill_on_the_gpu():
+    """BGP_FILL_MFMA=1 / BGP_FILL_TABLE=256 (read once per process: child processes) - the check of
+    tests/test_emu_kernels.py::test_optional_interior_paths_of_the_fill through the shipped library: elementwise error
+    of the filled entries against the oracle's kernel code, LML of a training fit, and bits that differ from the default
+    path's (the optional path was taken)."""
+    import json
+
+    script = os.path.join(HERE, "emu", "fill_variant_check.py")
+    envs = {"default": {}, "mfma": {"BGP_FILL_MFMA": "1"}, "mfma+t256": {"BGP_FILL_MFMA": "1", "BGP_FILL_TABLE": "256"}, "t256": {"BGP_FILL_TABLE": "256"}}
+    res = {}
+    for k, e in envs.items():
+        try:
+            r = subprocess.run([sys.executable, script, "--gpu", "3000"], env=dict(os.environ, **e), capture_output=True, text=True, timeout=600)
+        except subprocess.TimeoutExpired:
+            pytest.fail(f"fill variant {k}: no result within 600 s")
+        assert r.returncode == 0, f"fill variant {k}: rc = {r.returncode}\n{r.stderr[-2000:]}"
+        res[k] = json.loads(r.stdout.strip().splitlines()[-1])
+    for k, rr in res.items():
+        for kid, v in rr.items():
+            assert v["cross_max_rel"] < 2e-13 and v["lml_rel"] < 1e-9, (k, kid, v)
+    for k in ("mfma", "mfma+t256", "t256"):
+        for kid in res[k]:
+            assert res[k][kid]["factor_digest"] != res["default"][kid]["factor_digest"], (k, kid)

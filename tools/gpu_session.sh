@@ -63,6 +63,8 @@ if has fill; then
   stamp "steady fill"
   timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate.txt 2>&1
   BGP_FILL_TABLE=256 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_table256.txt 2>&1
+  BGP_FILL_MFMA=1 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_mfma.txt 2>&1
+  BGP_FILL_MFMA=1 BGP_FILL_TABLE=256 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_mfma_table256.txt 2>&1
 fi
 if has sharded; then
   stamp "sharded driver, single-rank proxy"
