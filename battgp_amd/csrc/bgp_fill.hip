@@ -265,7 +265,7 @@ typedef double fill_v4d __attribute__((ext_vector_type(4)));
 // Rounding: |error(q)| <~ 4 eps (|a'|^2 + |b'|^2); tiles with |a'|^2 or |b'|^2 above FILL_MFMA_LIMIT take the VALU path
 // (return false), so the entry's relative error stays below ~1e-13 (d g / g = dq / (2 (1 + r)) for Matern-3/2, dq for
 // the squared-exponential kernels) - inside the 2e-13 elementwise parity bound, an order of magnitude above the VALU path.
-constexpr double FILL_MFMA_LIMIT = 96.0;
+constexpr double FILL_MFMA_LIMIT = 64.0;
 
 template <int KID, bool T256>
 __device__ __forceinline__ bool fill_interior_mfma(const FillParams& p, const double* __restrict__ x1, int64_t i0, int64_t j0,
