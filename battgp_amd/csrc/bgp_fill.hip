@@ -42,14 +42,15 @@ __device__ const double EXP2_TBL[64] = {
 // no v_rndne / v_cvt pair.  One LDS table read per call; `tbl` may be pre-multiplied by an output scale.
 // FINITE = false: NaN stays NaN (it has to poison Sigma, not vanish in a clamp) and -inf gives 0;
 // FINITE = true (the fill's interior tiles, whose points were checked when they were staged): one VALU op less.
-template <bool FINITE>
+// BOUNDED: the caller guarantees -1.6e7 < x (the matrix-pipe tiles: |x| <= 256): no clamp at all.
+template <bool FINITE, bool BOUNDED = false>
 __device__ __forceinline__ double exp_nonpos_t(double x, const double* __restrict__ tbl) {
   const double INV = 92.33248261689366;      // 64 / ln2
   const double L_HI = 0.01083042469326756;  // ln2/64, low 21 bits zero: k * L_HI is exact
   const double L_LO = 2.9815858269852933e-12;
   const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
   const double LIM = -16777216.0;           // below: the result underflows to 0 anyway; keeps k inside 32 bits
-  x = FINITE ? __builtin_fmax(x, LIM) : ((x < LIM) ? LIM : x);
+  if (!BOUNDED) x = FINITE ? __builtin_fmax(x, LIM) : ((x < LIM) ? LIM : x);
   const double z = __builtin_fma(x, INV, MAGIC);
   const int k = __double2loint(z);
   const double kd = z - MAGIC;
@@ -72,12 +73,13 @@ __device__ __forceinline__ double exp_nonpos(double x, const double* __restrict_
 // The interior tiles' exponential: finite x <= 0, a 256-entry table 2^(i/256) (times the output scale) in LDS, so
 // |r| <= ln2/512 and a degree-4 polynomial suffices (truncation r^5/120 <= 3.8e-17): one FMA less per entry than
 // the 64-entry / degree-5 version above.
+template <bool BOUNDED = false>
 __device__ __forceinline__ double exp_interior(double x, const double* __restrict__ tbl256) {
   const double INV = 4.0 * 92.33248261689366;       // 256 / ln2
   const double L_HI = 0.25 * 0.01083042469326756;  // ln2/256 (the low bits stay zero under the power-of-two scaling)
   const double L_LO = 0.25 * 2.9815858269852933e-12;
   const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
-  x = __builtin_fmax(x, -4194304.0);        // keeps k = x * 256/ln2 inside 32 bits; the result is 0 there anyway
+  if (!BOUNDED) x = __builtin_fmax(x, -4194304.0);  // keeps k = x * 256/ln2 inside 32 bits; the result is 0 there anyway
   const double z = __builtin_fma(x, INV, MAGIC);
   const int k = __double2loint(z);
   const double kd = z - MAGIC;
@@ -336,19 +338,20 @@ __device__ __forceinline__ bool fill_interior_mfma(const FillParams& p, const do
     }
   }
   typedef double v2d __attribute__((ext_vector_type(2)));
+  // the guard above bounds every argument of the exponential: q <= (|a'| + |b'|)^2 <= 4 FILL_MFMA_LIMIT = 256
   auto entry = [&](double q, int a, int r, int b) -> double {
     if (KID == BGP_KERNEL_BATTGP) {
-      const double e = T256 ? exp_interior(-q, sTs) : exp_nonpos_t<true>(-q, sTs);  // s_r e^-q
+      const double e = T256 ? exp_interior<true>(-q, sTs) : exp_nonpos_t<true, true>(-q, sTs);  // s_r e^-q
       return __builtin_fma(w0[a][r], tr[b], w1[a][r]) + e;
     } else if (KID == BGP_KERNEL_MATERN32) {
       q = __builtin_fmax(q, 1e-300);  // cancellation may leave a tiny negative number at coincident points
       const double y = __builtin_amdgcn_rsq(q);
       double rr = q * y;
       rr = __builtin_fma(__builtin_fma(-rr, rr, q), 0.5 * y, rr);
-      const double se = T256 ? exp_interior(-rr, sTs) : exp_nonpos_t<true>(-rr, sTs);
+      const double se = T256 ? exp_interior<true>(-rr, sTs) : exp_nonpos_t<true, true>(-rr, sTs);
       return __builtin_fma(rr, se, se);
     } else {
-      return T256 ? exp_interior(-q, sTs) : exp_nonpos_t<true>(-q, sTs);
+      return T256 ? exp_interior<true>(-q, sTs) : exp_nonpos_t<true, true>(-q, sTs);
     }
   };
 #pragma unroll
