@@ -299,6 +299,8 @@ class BatteryCellGP:
 
     def set_raw_vector(self, raw) -> None:
         raw = np.asarray(raw, dtype=np.float64).reshape(-1)
+        if getattr(self, "_raw", None) is not None and np.array_equal(raw, self._raw):
+            return  # the optimiser came back to the point it last evaluated: the factor and the LML stay valid
         self._noise = float(self._c_noise.transform(raw[0]))
         self._outputscale_wiener = float(self._c_sw.transform(raw[1]))
         self._outputscale_rbf = float(self._c_sr.transform(raw[2]))

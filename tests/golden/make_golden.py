@@ -114,6 +114,83 @@ def make_stgp_egp(path: str) -> None:
     print("stgp_egp.npz ok")
 
 
+# ---- the same equivalence at production size and with the production hyper-parameters ---------------
+LONG_CHECKPOINTS = (1, 2, 3, 5, 10, 20, 50, 100, 200, 300, 400, 500, 1000, 1500, 2000)
+
+
+def make_stgp_long(path: str) -> None:
+    """``test_compare_stgp_egp`` (``tests/gp/test_spatiotemporal_gp.py:218-282``) carried from 10 to 500 / 2000 time steps
+    on the same kind of 20-point spatial basis, (a) with the test's hyper-parameters (``:226-230``) and (b) with the
+    numbers the product ships (``src/config.py:39-43``) on inputs in the production ranges (``src/config.py:99-111``).
+    The Kalman side is driven by the reference's own ``WienerTemporalKernel`` ``(A, Q)``
+    (``src/gp/wiener_kernel_temporal.py:28-35``) and never forms an N x N matrix: its posterior mean / variance at 50
+    query points after ``k`` observations and its summed innovation log-likelihood are what the exact GP on the first
+    ``k`` points must reproduce (mean, variance and LML at 1e-6 relative, the reference test's tolerance)."""
+    sys.path.insert(0, "/root/reference")
+    from src.gp.wiener_kernel_temporal import WienerTemporalKernel  # reference, pure numpy
+
+    rng = np.random.default_rng(20260930)
+    out = {"checkpoints": np.array(LONG_CHECKPOINTS, dtype=np.int64)}
+
+    def basis_prod(m):
+        return np.column_stack((rng.uniform(-80.0, -5.0, m), rng.uniform(40.0, 95.0, m), rng.uniform(10.0, 45.0, m)))
+
+    cases = []
+    # (a) the reference test's hyper-parameters; its target function over a full period of the temporal cosine
+    tt = np.unique(rng.uniform(0.0, 40.0, 500))
+    s_base = rng.uniform(-5.0, 5.0, (20, 3))
+    idx = rng.choice(20, len(tt))
+    cases.append(("test500", np.array([0.1, 10.0, 3.0, 2.0, 2.0, 2.0]), tt, s_base, idx, _foo(tt, s_base[idx]),
+                  rng.uniform(-5.0, 5.0, (50, 3))))
+    # (b) production hyper-parameters, production-shaped inputs (synthetic.make_cell_data's resistance model)
+    for name, n in (("prod500", 500), ("prod2000", 2000)):
+        tt = np.unique(rng.uniform(0.0, 1200.0, n))
+        tt[0] = 0.0
+        s_base = basis_prod(20)
+        idx = rng.choice(20, len(tt))
+        st = s_base[idx]
+        yt = 0.012 + 0.002 * np.exp(-(st[:, 2] - 10.0) / 20.0) + 1e-6 * tt + rng.normal(0.0, np.sqrt(synthetic.NOISE_VARIANCE), len(tt))
+        cases.append((name, synthetic.HYP_BATTGP.copy(), tt, s_base, idx, yt, basis_prod(50)))
+
+    for name, hyp, tt, s_base, idx, yt, sq in cases:
+        noise, s_w, s_r = float(hyp[0]), float(hyp[1]), float(hyp[2])
+        ref_kernel = WienerTemporalKernel(outputscale=s_w)
+        kf = KalmanSTGP(s_base, np.array([0.0, s_r, *hyp[3:]]), noise, ref_kernel.get_kalman_matrices)
+        st = s_base[idx]
+        xt = np.hstack((tt.reshape(-1, 1), st))
+        lmls, means, varis, steps = [], [], [], []
+        ll = 0.0
+        worst = [0.0, 0.0, 0.0]
+        for i in range(len(tt)):
+            kf.time_step(tt[i] - kf.t)
+            ll += kf.update(st[[i], :], yt[[i]])
+            lmls.append(ll)
+            if i + 1 in LONG_CHECKPOINTS:
+                m, v = kf.predict(sq)
+                steps.append(i + 1)
+                means.append(m)
+                varis.append(v)
+                # the oracle agrees at the reference's tolerance before anything is written
+                gp = OracleGP(K.KERNEL_BATTGP, hyp, xt[: i + 1], yt[: i + 1]).fit()
+                xq = np.hstack((np.full((sq.shape[0], 1), tt[i]), sq))
+                mo, vo = gp.predict(xq, clamp=False)
+                assert gp.jitter == 0.0
+                e = (abs(gp.lml - ll) / abs(ll), np.linalg.norm(mo - m) / np.linalg.norm(m), np.linalg.norm(vo - v) / np.linalg.norm(v))
+                assert max(e) < 1e-6, (name, i + 1, e)
+                worst = [max(a, b) for a, b in zip(worst, e)]
+        print(f"  {name}: {len(tt)} steps, oracle vs Kalman worst rel: lml {worst[0]:.1e} mean {worst[1]:.1e} var {worst[2]:.1e}")
+        out[name + "_hyp"] = hyp
+        out[name + "_xt"] = xt
+        out[name + "_yt"] = yt
+        out[name + "_sq"] = sq
+        out[name + "_steps"] = np.array(steps, dtype=np.int64)
+        out[name + "_kalman_lml"] = np.array(lmls)
+        out[name + "_kalman_mean"] = np.array(means)
+        out[name + "_kalman_var"] = np.array(varis)
+    np.savez_compressed(path, **out)
+    print("stgp_egp_long.npz ok")
+
+
 # ---- LML pins: torch.distributions on a covariance assembled the gpytorch way ------------------------
 def _gpytorch_sq_dist(x1, x2, x1_eq_x2):
     """gpytorch ``Kernel.covar_dist(square_dist=True)``: mean-centred quadratic expansion, self-diagonal
@@ -286,6 +363,7 @@ def make_n2048(path: str) -> None:
 
 if __name__ == "__main__":
     make_stgp_egp(os.path.join(HERE, "stgp_egp.npz"))
+    make_stgp_long(os.path.join(HERE, "stgp_egp_long.npz"))
     make_lml_pins(os.path.join(HERE, "lml_pins.npz"))
     make_oracle_cases(os.path.join(HERE, "oracle_cases.npz"))
     make_n2048(os.path.join(HERE, "oracle_n2048.json"))

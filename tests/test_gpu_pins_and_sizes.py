@@ -65,6 +65,31 @@ def test_lml_matches_kalman_innovation_likelihood(golden_dir):
         e.close()
 
 
+@pytest.mark.parametrize("name", ["test500", "prod500", "prod2000"])
+def test_stgp_egp_long_golden_on_gpu(golden_dir, name):
+    """tests/gp/test_spatiotemporal_gp.py:218-282 at 500 / 2000 time steps with the test's and the production
+    hyper-parameters (src/config.py:39-43): posterior mean, variance and LML of the HIP engine on the first k points
+    against the Kalman filter driven by the reference's WienerTemporalKernel (make_golden.py::make_stgp_long), at the
+    reference test's tolerance.  Both call shapes: fit + predict, and the fused fit_predict."""
+    g = np.load(os.path.join(golden_dir, "stgp_egp_long.npz"))
+    hyp, xt, yt, sq = g[name + "_hyp"], g[name + "_xt"], g[name + "_yt"], g[name + "_sq"]
+    e = ExactGPEngine(K.KERNEL_BATTGP, hyp)
+    try:
+        for row, k in enumerate(g[name + "_steps"]):
+            xq = np.hstack((np.full((sq.shape[0], 1), xt[k - 1, 0]), sq))
+            lml = e.fit(xt[:k], yt[:k])
+            assert e.jitter == 0.0
+            m, v = e.predict(xq, min_var=-1.0)
+            lml2, m2, v2 = e.fit_predict(xt[:k], yt[:k], xq, min_var=-1.0)
+            want = g[name + "_kalman_lml"][k - 1]
+            for ll, mm, vv in ((lml, m, v), (lml2, m2, v2)):
+                assert abs(ll - want) <= REL * abs(want), (k, ll, want)
+                assert np.linalg.norm(mm - g[name + "_kalman_mean"][row]) <= REL * np.linalg.norm(mm), k
+                assert np.linalg.norm(vv - g[name + "_kalman_var"][row]) <= REL * np.linalg.norm(vv), k
+    finally:
+        e.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # (b) natural sizes
 # ---------------------------------------------------------------------------------------------

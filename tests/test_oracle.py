@@ -90,6 +90,28 @@ def test_lml_pinned_by_kalman_innovation_likelihood(golden_dir):
         assert abs(gp.lml - want) < 1e-6 * abs(want), (i, gp.lml, want)
 
 
+LONG_CASES = ["test500", "prod500", "prod2000"]
+
+
+@pytest.mark.parametrize("name", LONG_CASES)
+def test_stgp_egp_long_golden(golden_dir, name):
+    """The reference's exact-GP == Kalman-stGP cross-check (tests/gp/test_spatiotemporal_gp.py:218-282) at 500 / 2000
+    time steps, with the test's and with the PRODUCTION hyper-parameters (src/config.py:39-43); Kalman side driven by
+    the reference's WienerTemporalKernel (tests/golden/make_golden.py::make_stgp_long).  Mean, variance and LML of the
+    exact GP on the first k points at the reference test's tolerance, 1e-6 relative."""
+    g = np.load(os.path.join(golden_dir, "stgp_egp_long.npz"))
+    hyp, xt, yt, sq = g[name + "_hyp"], g[name + "_xt"], g[name + "_yt"], g[name + "_sq"]
+    for row, k in enumerate(g[name + "_steps"]):
+        gp = OracleGP(K.KERNEL_BATTGP, hyp, xt[:k], yt[:k]).fit()
+        assert gp.jitter == 0.0
+        xq = np.hstack((np.full((sq.shape[0], 1), xt[k - 1, 0]), sq))
+        m, v = gp.predict(xq, clamp=False)
+        want = g[name + "_kalman_lml"][k - 1]
+        assert abs(gp.lml - want) < 1e-6 * abs(want), (k, gp.lml, want)
+        assert np.linalg.norm(m - g[name + "_kalman_mean"][row]) < 1e-6 * np.linalg.norm(m), k
+        assert np.linalg.norm(v - g[name + "_kalman_var"][row]) < 1e-6 * np.linalg.norm(v), k
+
+
 LML_PIN_CASES = [(name, n) for name in ("k0prod", "k0test", "k1") for n in (10, 64, 512)]
 
 
