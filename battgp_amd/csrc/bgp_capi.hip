@@ -118,12 +118,22 @@ int phase_events(bgp_handle* h, int slot, hipEvent_t* begin, hipEvent_t* end) {
   return 0;
 }
 
-// reads every recorded-but-unread phase; call only behind a synchronisation of the stream(s) they were recorded on
+// reads every recorded-but-unread phase whose end event has completed (normally all of them: the callers sit behind a
+// synchronisation of the stream the events were recorded on).  A slot that is not ready - an error return between
+// stop_async() and the synchronisation leaves one behind - stays pending and is read by a later call; timing is
+// bookkeeping and never turns into an error of the entry point (h->err keeps the message of the real failure).
 int collect_phases(bgp_handle* h) {
   for (int slot = 0; slot < BGP_T_COUNT && h->phase_pending; ++slot) {
     if (!(h->phase_pending & (1u << slot))) continue;
+    if (hipEventQuery(h->ev_phase[2 * slot + 1]) != hipSuccess) {
+      (void)hipGetLastError();  // hipErrorNotReady is sticky in the per-thread last-error slot
+      continue;
+    }
     float ms = 0.f;
-    BGP_HIP(h, hipEventElapsedTime(&ms, h->ev_phase[2 * slot], h->ev_phase[2 * slot + 1]));
+    if (hipEventElapsedTime(&ms, h->ev_phase[2 * slot], h->ev_phase[2 * slot + 1]) != hipSuccess) {
+      (void)hipGetLastError();
+      ms = 0.f;
+    }
     if (h->phase_acc & (1u << slot)) h->times[slot] += ms;
     else h->times[slot] = ms;
     h->phase_pending &= ~(1u << slot);
@@ -693,14 +703,13 @@ void free_problem(bgp_handle* h) {
   dev_free(h, &h->dy, h->N);
   dev_free(h, &h->dE, h->E_rows_cap * h->Npad);
   h->E_rows_cap = 0;
-  dev_free(h, &h->dB, h->B_ld * h->B_n);
-  h->B_ld = h->B_n = 0;
   dev_free(h, &h->dLinvAll, h->LinvAll_cap);
   h->LinvAll_cap = 0;
   h->LinvAll_nb = 0;
   h->N = h->Npad = h->lda = 0;
   h->D = 0;
   h->fitted = false;
+  h->factor_consumed = false;
   h->has_data = false;
   h->t_sorted = false;
 }
@@ -791,6 +800,7 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mri
   const int64_t N = h->N, Npad = h->Npad;
   const SlabView V = h->view();
   h->fitted = false;
+  h->factor_consumed = false;  // the storage is refilled below
   h->LinvAll_nb = 0;
   h->times[BGP_T_FILL] = h->times[BGP_T_POTRF] = h->times[BGP_T_CROSS] = 0.0;
   const int64_t ride_rows = round_up(Mride, 64);
@@ -880,6 +890,19 @@ int ensure_alpha(bgp_handle* h) {
   if (rc) return rc;
   if ((rc = t.stop())) return rc;
   h->alpha_ready = true;
+  return 0;
+}
+
+// bgp_lml_grad turns the factor into Sigma^-1 IN PLACE (no second N^2 buffer).  A call that needs L afterwards - a
+// prediction at the optimum, a residual check, another gradient at the same point - gets it back here: same resident
+// data, same hyper-parameters, same jitter ladder, so the factor, z and the LML come out bit-identical (the optimiser
+// loops re-fit with new hyper-parameters before every gradient anyway: src/gp/training.py:39-41).
+int ensure_factor(bgp_handle* h) {
+  if (!h->factor_consumed) return 0;
+  const bool alpha_was_ready = h->alpha_ready;  // alpha lives in its own vector and stays what it was
+  int rc = fit_resident(h, nullptr, nullptr, 0);
+  if (rc) return rc;
+  h->alpha_ready = alpha_was_ready;
   return 0;
 }
 
@@ -1075,6 +1098,7 @@ void reset_logical(bgp_handle* h) {
   h->has_data = false;
   h->t_sorted = false;
   h->alpha_ready = false;
+  h->factor_consumed = false;
   h->jitter_used = 0.0;
   h->lml = 0.0;
   for (double& t : h->times) t = 0.0;
@@ -1372,6 +1396,7 @@ static int predict_common(bgp_handle* h, const double* Xq, int64_t M, double* me
   if (rc) return rc;
   if (!h->fitted) return bgp_fail(h, -1, "bgp_predict: no successful fit on this handle");
   if (!Xq || M < 1 || !mean) return bgp_fail(h, -1, "bgp_predict: bad arguments (M=%lld)", (long long)M);
+  if ((rc = ensure_factor(h))) return rc;
   if ((rc = ensure_query(h, M))) return rc;
   hipStream_t st = h->s_main;
   const hipMemcpyKind kin = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1402,6 +1427,7 @@ int bgp_predict_cov(bgp_handle* h, const double* Xq_host, int64_t M, double* mea
   if (rc) return rc;
   if (!h->fitted) return bgp_fail(h, -1, "bgp_predict_cov: no successful fit on this handle");
   if (!Xq_host || M < 1 || !mean_out || !cov_out) return bgp_fail(h, -1, "bgp_predict_cov: bad arguments");
+  if ((rc = ensure_factor(h))) return rc;
   if ((rc = ensure_query(h, M))) return rc;
   hipStream_t st = h->s_main;
   const int64_t Mpad = round_up(M, 16);
@@ -1461,6 +1487,7 @@ int bgp_get_alpha(bgp_handle* h, double* alpha_host) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!h->fitted || !alpha_host) return bgp_fail(h, -1, "bgp_get_alpha: no fit / NULL output");
+  if (!h->alpha_ready && (rc = ensure_factor(h))) return rc;
   if ((rc = ensure_alpha(h))) return rc;
   BGP_HIP(h, hipMemcpyAsync(alpha_host, h->dalpha, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->s_main));
   BGP_HIP(h, hipStreamSynchronize(h->s_main));
@@ -1471,6 +1498,7 @@ int bgp_residuals(bgp_handle* h, int nsample, double* out2) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!h->fitted || !out2) return bgp_fail(h, -1, "bgp_residuals: no fit / NULL output");
+  if ((rc = ensure_factor(h))) return rc;
   if ((rc = ensure_alpha(h))) return rc;
   if (nsample < 2) nsample = 2;
   if (nsample > 65536) nsample = 65536;
@@ -1501,6 +1529,7 @@ int bgp_get_factor_rows(bgp_handle* h, const int64_t* rows, int nrows, double* o
   int rc = check_handle(h);
   if (rc) return rc;
   if (!h->fitted || !rows || !out_host || nrows < 1) return bgp_fail(h, -1, "bgp_get_factor_rows: no fit / bad arguments");
+  if ((rc = ensure_factor(h))) return rc;
   const int64_t N = h->N;
   if ((rc = ensure_part(h, N))) return rc;
   hipStream_t st = h->s_main;
@@ -1524,6 +1553,7 @@ int bgp_get_factor_diag(bgp_handle* h, double* diag_host) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!h->fitted || !diag_host) return bgp_fail(h, -1, "bgp_get_factor_diag: no fit / NULL output");
+  if ((rc = ensure_factor(h))) return rc;
   const int64_t N = h->N, Npad = h->Npad;
   if ((rc = ensure_part(h, Npad))) return rc;
   hipStream_t st = h->s_main;
@@ -1819,96 +1849,8 @@ int bgp_sync(bgp_handle* h) {
   return 0;
 }
 
-int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (!h->fitted || !grad_out) return bgp_fail(h, -1, "bgp_lml_grad: no successful fit / NULL output");
-  if (ngrad != h->nhyp) return bgp_fail(h, -1, "bgp_lml_grad: expected %d entries, got %d", h->nhyp, ngrad);
-  hipStream_t st = h->s_main;
-  const int64_t N = h->N, n = h->Npad, NB = h->nb_outer;
-  // ONE extra square: U = L^-T (upper) is built in it and then overwritten IN PLACE by the upper triangle of
-  // P = U U^T = Sigma^-1 (blocked LAUUM, every product in the NT form of the MFMA kernel)
-  int64_t ldb = n;
-  if (ldb >= 2048 && (ldb % 512) == 0) ldb += 64;
-  if (h->dB && h->B_ld != ldb) {
-    dev_free(h, &h->dB, h->B_ld * h->B_n);
-    h->B_ld = h->B_n = 0;
-  }
-  if (!h->dB) {
-    if ((rc = dev_alloc(h, &h->dB, ldb * n))) return rc;
-    h->B_ld = ldb;
-    h->B_n = n;
-  }
-  double* U = h->dB;
-  const SlabView L = h->view();
-  const double* inv = h->dInv;
-  PhaseTimer t(h, st, BGP_T_SOLVE);
-  // (1) U = I L^-T (upper triangular): the identity pushed through the panel operations row-block-wise;
-  //     a row only becomes active at the panel that contains its diagonal element  -> N^3/3 flop.
-  //     The strict lower triangle of the square stays exactly zero (step (2) relies on it).
-  if ((rc = launch_set_identity(h, st, U, ldb, n))) return rc;
-  for (int64_t K0 = 0; K0 < n; K0 += NB) {
-    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
-    const int64_t K1 = K0 + nbk;
-    for (int64_t j = K0; j < K1; j += BGP_IB) {
-      const int64_t act = j + BGP_IB;  // active rows [0, act)
-      double* Uj = U + j * ldb;
-      if ((rc = launch_gemm_nt(h, st, 1, 64, Uj, ldb, Uj, ldb, inv + (j / BGP_IB) * (BGP_IB * BGP_IB), BGP_IB, act,
-                               BGP_IB, BGP_IB, 0)))
-        return rc;
-      const int64_t ncols = K1 - (j + BGP_IB);
-      if (ncols > 0 &&
-          (rc = launch_gemm_nt(h, st, 0, ncols >= 128 ? 128 : 64, U + (j + BGP_IB) * ldb, ldb, Uj, ldb,
-                               L.at(j + BGP_IB, j), L.ld(j), act, ncols, BGP_IB, 0)))
-        return rc;
-    }
-    if (n - K1 > 0 && (rc = launch_gemm_nt(h, st, 0, 128, U + K1 * ldb, ldb, U + K0 * ldb, ldb, L.at(K1, K0), L.ld(K0),
-                                           K1, n - K1, nbk, 0)))
-      return rc;
-  }
-  // alpha = L^-T z = U z comes for one pass over U (the panel-wise backward solve costs one latency-bound
-  // single-workgroup kernel per outer panel: 0.3 of 1.8 ms at N = 1000)
-  if (!h->alpha_ready) {
-    if ((rc = ensure_part(h, ((n + BGP_RD_COLS - 1) / BGP_RD_COLS + 1) * n))) return rc;
-    int nch = 0;
-    if ((rc = launch_rowdot(h, st, U, ldb, n, n, h->dz, h->dpart, &nch))) return rc;
-    FillParams p0;
-    memset(&p0, 0, sizeof(p0));
-    if ((rc = launch_rowdot_finish(h, st, h->dpart, nch, n, nullptr, &p0, -1.0, h->dalpha))) return rc;
-    h->alpha_ready = true;
-  }
-  // (2) P = U U^T in place, upper triangle, panel by panel from the left (a panel only reads columns to its right,
-  //     which are still U):
-  //       P[0:c0, p]   = U[0:c0, p] U_pp^T                      (through a workspace: the product is not in place)
-  //       P_pp         = U_pp U_pp^T                            (ditto; the whole symmetric block is written)
-  //       P[0:c1, p]  += U[0:c1, c1:n] U[c0:c1, c1:n]^T         (one deep NT GEMM, MODE 3)       -> N^3/3 flop
-  if ((rc = ensure_part(h, n * NB + NB * NB))) return rc;
-  double* Wtall = h->dpart;           // [c0, nb], ld = c0
-  double* Wdiag = h->dpart + n * NB;  // [nb, nb]
-  for (int64_t c0 = 0; c0 < n; c0 += NB) {
-    const int64_t nb = (n - c0 < NB) ? (n - c0) : NB;
-    const int64_t c1 = c0 + nb;
-    double* Upp = U + c0 + c0 * ldb;
-    double* Ucol = U + c0 * ldb;  // rows 0.. of the panel's columns
-    if (c0 > 0) {
-      if ((rc = launch_gemm_nt(h, st, 1, 64, Wtall, c0, Ucol, ldb, Upp, ldb, c0, nb, nb, 0))) return rc;
-      if ((rc = launch_copy_panel(h, st, Wtall, c0, Ucol, ldb, c0, (int)nb))) return rc;
-    }
-    if ((rc = launch_gemm_nt(h, st, 1, 64, Wdiag, nb, Upp, ldb, Upp, ldb, nb, nb, nb, 0))) return rc;
-    if ((rc = launch_copy_panel(h, st, Wdiag, nb, Upp, ldb, nb, (int)nb))) return rc;
-    if (c1 < n && (rc = launch_gemm_nt(h, st, 3, 128, Ucol, ldb, U + c1 * ldb, ldb, U + c0 + c1 * ldb, ldb, c1, nb, n - c1, 0)))
-      return rc;
-  }
-  // (3) fused reduction of 1/2 tr(W dSigma/dtheta)
-  FillParams p;
-  if ((rc = make_fill_params(h, h->D, 0.0, &p))) return rc;
-  const int64_t nblk = grad_blocks(N);
-  const int nacc = grad_nacc();
-  if ((rc = ensure_part(h, nblk * nacc))) return rc;
-  if ((rc = launch_grad_reduce(h, st, p, h->dX, N, U, ldb, h->dalpha, h->dpart, h->dscal))) return rc;
-  BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, nacc * sizeof(double), hipMemcpyDeviceToHost, st));
-  if ((rc = t.stop())) return rc;
-  const double* a = h->hscal;
+// accumulators of the reduction pass (grad_reduce_kernel) -> d lml / d theta in the hyper-parameter layout
+static void grad_from_acc(const bgp_handle* h, const double* a, double* grad_out, int ngrad) {
   const int D = h->D;
   for (int i = 0; i < ngrad; ++i) grad_out[i] = 0.0;
   grad_out[0] = 0.5 * a[0];
@@ -1935,6 +1877,115 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
       for (int d = 0; d < D; ++d) grad_out[2 + d] = 0.5 * h->hyp[1] / h->hyp[2 + d] * a[3 + d];
       break;
   }
+}
+
+int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->fitted || !grad_out) return bgp_fail(h, -1, "bgp_lml_grad: no successful fit / NULL output");
+  if (ngrad != h->nhyp) return bgp_fail(h, -1, "bgp_lml_grad: expected %d entries, got %d", h->nhyp, ngrad);
+  if ((rc = ensure_factor(h))) return rc;  // a previous gradient at this point consumed it
+  if ((rc = ensure_alpha(h))) return rc;   // alpha = L^-T z, while L is still L
+  hipStream_t st = h->s_main;
+  const int64_t N = h->N, n = h->Npad, NB = h->nb_outer;
+  const SlabView V = h->view();
+  // workspaces, all inside dpart: two transposed row blocks [n, NB], two NB x NB blocks, the partial sums of the reduction
+  int64_t ldt = n;
+  if (ldt >= 2048 && (ldt % 512) == 0) ldt += 64;
+  const int nacc = grad_nacc();
+  int64_t red_blocks = 0;
+  for (int64_t c0 = 0; c0 < n;) {
+    const int64_t c1 = V.slab_end(c0, n);
+    red_blocks = std::max(red_blocks, grad_blocks(n - c0, c1 - c0));
+    c0 = c1;
+  }
+  if ((rc = ensure_panel_inverses(h, st))) return rc;  // inv(L_pp) of every outer panel, from the intact factor
+  if ((rc = ensure_part(h, std::max(2 * ldt * NB + 2 * NB * NB, red_blocks * nacc)))) return rc;
+  double* Wt1 = h->dpart;
+  double* Wt2 = Wt1 + ldt * NB;
+  double* Ms = Wt2 + ldt * NB;  // [NB, NB] clean lower-triangular M_kk = inv(L_kk)
+  double* Mt = Ms + NB * NB;    // [NB, NB] its transpose (negated in step A)
+  PhaseTimer t(h, st, BGP_T_SOLVE);
+  h->factor_consumed = true;  // from here on the storage no longer holds a factor, whatever happens below
+  // row block [K0, K0 + nbk) x columns [0, K0) of the stored triangle <-> its transpose Wt[0:K0, 0:nbk] (one launch per slab)
+  auto row_block = [&](int64_t K0, int64_t nbk, double* Wt, bool out) -> int {
+    for (int64_t c_lo = 0; c_lo < K0;) {
+      const int64_t c_hi = V.slab_end(c_lo, K0);
+      int r = out ? launch_block_copy(h, st, V.at(K0, c_lo), V.ld(c_lo), nbk, c_hi - c_lo, Wt + c_lo, ldt, 1, 1.0, 0)
+                  : launch_block_copy(h, st, Wt + c_lo, ldt, c_hi - c_lo, nbk, V.at(K0, c_lo), V.ld(c_lo), 1, 1.0, 0);
+      if (r) return r;
+      c_lo = c_hi;
+    }
+    return 0;
+  };
+  // (A) M = L^-1 in place, right-looking over the column panels (L = C_0 C_1 ... C_{p-1}, C_k = the identity with column
+  //     panel k of L; M = C_{p-1}^-1 ... C_0^-1 applied to X = I from the left, X stored where L was).  Step k:
+  //       X[k, 0:K0]   <- M_kk X[k, 0:K0]                 (as Wt2 = Wt1 M_kk^T on the transposed row block)
+  //       X[K1:, 0:K0] -= L[K1:, k] X[k, 0:K0]            (ONE deep rank-nb update per slab: the N^3/3 flop of this step,
+  //                                                        same kernel and epilogue as the Cholesky's trailing update)
+  //       X[K1:, k]     = -L[K1:, k] M_kk,  X_kk = M_kk   (through a workspace: the product is not in place)
+  //     Only panel k of L is read at step k, and it is overwritten last.
+  for (int64_t K0 = 0, pidx = 0; K0 < n; K0 += NB, ++pidx) {
+    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    const int64_t K1 = K0 + nbk, below = n - K1;
+    const double* Linv = h->dLinvAll + pidx * NB * NB;
+    if ((rc = launch_block_copy(h, st, Linv, NB, nbk, nbk, Ms, NB, 0, 1.0, 1))) return rc;
+    if (K0 > 0) {
+      if ((rc = row_block(K0, nbk, Wt1, true))) return rc;
+      if ((rc = launch_gemm_nt(h, st, 1, 64, Wt2, ldt, Wt1, ldt, Ms, NB, K0, nbk, nbk, 0, nullptr, 1))) return rc;
+      if ((rc = row_block(K0, nbk, Wt2, false))) return rc;
+      const int tmode = nbk >= 256 ? 2 : 0;
+      for (int64_t c_lo = 0; below > 0 && c_lo < K0;) {
+        const int64_t c_hi = V.slab_end(c_lo, K0);
+        if ((rc = launch_gemm_nt(h, st, tmode, 128, V.at(K1, c_lo), V.ld(c_lo), V.at(K1, K0), V.ld(K0), Wt2 + c_lo, ldt, below,
+                                 c_hi - c_lo, nbk, 0)))
+          return rc;
+        c_lo = c_hi;
+      }
+    }
+    if (below > 0) {
+      if ((rc = launch_block_copy(h, st, Linv, NB, nbk, nbk, Mt, NB, 1, -1.0, 1))) return rc;  // -M_kk^T
+      if ((rc = launch_gemm_nt(h, st, 1, 64, Wt1, ldt, V.at(K1, K0), V.ld(K0), Mt, NB, below, nbk, nbk, 0))) return rc;
+      if ((rc = launch_copy_panel(h, st, Wt1, ldt, V.at(K1, K0), V.ld(K0), below, (int)nbk))) return rc;
+    }
+    if ((rc = launch_copy_panel(h, st, Ms, NB, V.at(K0, K0), V.ld(K0), nbk, (int)nbk))) return rc;
+  }
+  // (B) P = M^T M = Sigma^-1 in place (lower triangle), row blocks from the top:  step k
+  //       P[0:K0, 0:K0] += M[k, 0:K0]^T M[k, 0:K0]       (rank-nb SYRK of the LEADING block per slab: the N^3/3 flop)
+  //       M[k, 0:K0]    <- M_kk^T M[k, 0:K0]              (as Wt2 = Wt1 M_kk on the transposed row block)
+  //       P_kk           = M_kk^T M_kk                    (the whole symmetric block is written)
+  //     Row block k is untouched until its own step, and the leading block only collects finished contributions.
+  for (int64_t K0 = 0; K0 < n; K0 += NB) {
+    const int64_t nbk = (n - K0 < NB) ? (n - K0) : NB;
+    if ((rc = launch_block_copy(h, st, V.at(K0, K0), V.ld(K0), nbk, nbk, Mt, NB, 1, 1.0, 1))) return rc;  // M_kk^T
+    if (K0 > 0) {
+      if ((rc = row_block(K0, nbk, Wt1, true))) return rc;
+      for (int64_t c_lo = 0; c_lo < K0;) {
+        const int64_t c_hi = V.slab_end(c_lo, K0);
+        if ((rc = launch_gemm_nt(h, st, 3, 128, V.at(c_lo, c_lo), V.ld(c_lo), Wt1 + c_lo, ldt, Wt1 + c_lo, ldt, K0 - c_lo,
+                                 c_hi - c_lo, nbk, 1)))
+          return rc;
+        c_lo = c_hi;
+      }
+      if ((rc = launch_gemm_nt(h, st, 1, 64, Wt2, ldt, Wt1, ldt, Mt, NB, K0, nbk, nbk, 0))) return rc;
+      if ((rc = row_block(K0, nbk, Wt2, false))) return rc;
+    }
+    if ((rc = launch_gemm_nt(h, st, 1, 64, V.at(K0, K0), V.ld(K0), Mt, NB, Mt, NB, nbk, nbk, nbk, 0))) return rc;
+  }
+  // (C) fused reduction of 1/2 tr((alpha alpha^T - P) dSigma/dtheta), slab by slab
+  FillParams p;
+  if ((rc = make_fill_params(h, h->D, 0.0, &p))) return rc;
+  BGP_HIP(h, hipMemsetAsync(h->dscal, 0, nacc * sizeof(double), st));
+  for (int64_t c0 = 0; c0 < n;) {
+    const int64_t c1 = V.slab_end(c0, n);
+    if (c0 < N && (rc = launch_grad_reduce(h, st, p, h->dX, N, c0, n - c0, c1 - c0, V.at(c0, c0), V.ld(c0), h->dalpha, h->dpart,
+                                           h->dscal, 1)))
+      return rc;
+    c0 = c1;
+  }
+  BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, nacc * sizeof(double), hipMemcpyDeviceToHost, st));
+  if ((rc = t.stop())) return rc;
+  grad_from_acc(h, h->hscal, grad_out, ngrad);
   return 0;
 }
 

@@ -513,9 +513,11 @@ __global__ __launch_bounds__(64) void llt_sample_kernel(FillParams p, const doub
 
 
 // ---- LML gradient reduction ------------------------------------------------------------------
-//   d lml / d theta = 1/2 sum_jk W_jk dSigma_jk/dtheta,   W = alpha alpha^T - P,  P = Sigma^-1 (UPPER triangle stored)
-// One pass over the upper triangle (512 x 32 tiles, rows contiguous like the fill), kernel derivatives
-// re-evaluated on the fly, NACC partial sums per workgroup (deterministic two-stage reduction):
+//   d lml / d theta = 1/2 sum_jk W_jk dSigma_jk/dtheta,   W = alpha alpha^T - P,  P = Sigma^-1 (LOWER triangle stored)
+// One pass over a lower trapezoid of P that starts ON the diagonal - rows [r0, r0 + nrows) x columns [r0, r0 + ncols)
+// of the matrix: a column slab of the single-GPU layout or one column panel of the sharded one, element (i, j) at
+// P[(i - r0) + (j - r0) ldp] - in 512 x 32 tiles, rows contiguous like the fill; kernel derivatives re-evaluated on the
+// fly, NACC partial sums per workgroup (deterministic two-stage reduction):
 //   acc[0] = sum W_jj (j < N)                              -> d/d noise
 //   acc[1] = sum' W_jk * wiener(t_j, t_k)      (K0 only)   -> d/d s_wiener
 //   acc[2] = sum' W_jk * g_jk,  g = exp part ((1+r) e^-r for Matern)      -> d/d outputscale
@@ -523,29 +525,10 @@ __global__ __launch_bounds__(64) void llt_sample_kernel(FillParams p, const doub
 // where sum' counts each off-diagonal pair twice (symmetry) and the diagonal once.
 constexpr int GR_NACC = 3 + BGP_MAX_DIM;
 
-// upper trapezoid: column tile tj (32 columns) needs the row tiles ti <= tj / FT_RATIO (512 rows each).  Column tiles
-// are grouped by g = tj / FT_RATIO: FT_RATIO column tiles x (g + 1) row tiles;  prefix(g) = FT_RATIO g (g + 1) / 2.
-__device__ __forceinline__ bool upper_decode(int64_t t, int ntj, int& ti, int& tj) {
-  auto prefix = [&](int64_t q) { return (int64_t)FT_RATIO * q * (q + 1) / 2; };
-  int64_t g = (int64_t)((__builtin_sqrt(1.0 + 8.0 * (double)t / FT_RATIO) - 1.0) * 0.5);
-  if (g < 0) g = 0;
-  while (g > 0 && prefix(g) > t) --g;
-  while (prefix(g + 1) <= t) ++g;
-  const int64_t r = t - prefix(g);
-  tj = (int)(g * FT_RATIO + r / (g + 1));
-  ti = (int)(r % (g + 1));
-  return tj < ntj;
-}
-
-__host__ int64_t upper_blocks(int ntj) {
-  const int64_t G = (ntj + FT_RATIO - 1) / FT_RATIO;
-  return (int64_t)FT_RATIO * G * (G + 1) / 2;
-}
-
 template <int KID>
-__global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const double* __restrict__ x, int64_t n,
+__global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const double* __restrict__ x, int64_t n, int64_t r0,
                                                           const double* __restrict__ P, int64_t ldp,
-                                                          const double* __restrict__ alpha, int ntj,
+                                                          const double* __restrict__ alpha, int nti, int ntj,
                                                           double* __restrict__ part) {
   constexpr int DD = BGP_MAX_DIM;
   const int D = p.D;
@@ -559,9 +542,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const do
   for (int q = 0; q < GR_NACC; ++q) acc[q] = 0.0;
 
   int ti, tj;
-  const bool valid_tile = upper_decode((int64_t)blockIdx.x, ntj, ti, tj);
+  const bool valid_tile = lower_decode((int64_t)blockIdx.x, nti, ntj, ti, tj);
   if (valid_tile) {
-    const int64_t i0 = (int64_t)ti * FT_ROWS, j0 = (int64_t)tj * FT_COLS;
+    const int64_t i0 = r0 + (int64_t)ti * FT_ROWS, j0 = r0 + (int64_t)tj * FT_COLS;
     for (int idx = threadIdx.x; idx < FT_COLS * DD; idx += 256) {
       int c = idx / DD, d = idx % DD;
       int64_t j = j0 + c;
@@ -588,9 +571,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const do
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int64_t ii = i + r;
-        if (ii > j) continue;  // strict lower triangle (and, since j < n, everything past the matrix)
+        if (ii < j || ii >= n) continue;  // strict upper triangle of the block; rows past the matrix (padding)
         const double wgt = (ii == j) ? 1.0 : 2.0;
-        const double W = wgt * (al[r] * sAl[c] - P[ii + j * ldp]);
+        const double W = wgt * (al[r] * sAl[c] - P[(ii - r0) + (j - r0) * ldp]);
         if (ii == j) acc[0] += W;
         double q = 0.0, u2[DD];
 #pragma unroll
@@ -638,9 +621,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const do
         (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
 }
 
-// out[q] = sum_b part[b * GR_NACC + q]   (one workgroup, fixed order => run-to-run identical)
+// out[q] (+)= sum_b part[b * GR_NACC + q]   (one workgroup, fixed order => run-to-run identical)
 __global__ __launch_bounds__(1024) void grad_finish_kernel(const double* __restrict__ part, int64_t nblocks,
-                                                           double* __restrict__ out) {
+                                                           double* __restrict__ out, int accumulate) {
   __shared__ double red[1024];
   for (int q = 0; q < GR_NACC; ++q) {
     double v = 0.0;
@@ -651,7 +634,7 @@ __global__ __launch_bounds__(1024) void grad_finish_kernel(const double* __restr
       if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) out[q] = red[0];
+    if (threadIdx.x == 0) out[q] = accumulate ? out[q] + red[0] : red[0];
     __syncthreads();
   }
 }
@@ -699,16 +682,22 @@ int launch_llt_sample(bgp_handle* h, hipStream_t st, const FillParams& p, const 
 
 int grad_nacc() { return GR_NACC; }
 
-int64_t grad_blocks(int64_t n) { return upper_blocks((int)((n + FT_COLS - 1) / FT_COLS)); }
+int64_t grad_blocks(int64_t nrows, int64_t ncols) {
+  return lower_blocks((int)((nrows + FT_ROWS - 1) / FT_ROWS), (int)((ncols + FT_COLS - 1) / FT_COLS));
+}
 
-int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n,
-                       const double* P, int64_t ldp, const double* alpha, double* part, double* out) {
-  const int ntj = (int)((n + FT_COLS - 1) / FT_COLS);
-  const int64_t nb = upper_blocks(ntj);
-  BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((grad_reduce_kernel<KID_>), dim3((unsigned)nb), dim3(256), 0, st, p, x, n, P,
-                                           ldp, alpha, ntj, part));
+// one lower trapezoid of P (see grad_reduce_kernel); out[0 .. GR_NACC) receives (accumulate: is increased by) its sums
+int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n, int64_t r0,
+                       int64_t nrows, int64_t ncols, const double* P, int64_t ldp, const double* alpha, double* part,
+                       double* out, int accumulate) {
+  const int nti = (int)((nrows + FT_ROWS - 1) / FT_ROWS), ntj = (int)((ncols + FT_COLS - 1) / FT_COLS);
+  const int64_t nb = lower_blocks(nti, ntj);
+  if (nb <= 0) return 0;
+  if (nb > 0x7fffffffLL) return bgp_fail(h, -1, "grad_reduce: grid too large");
+  BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((grad_reduce_kernel<KID_>), dim3((unsigned)nb), dim3(256), 0, st, p, x, n, r0, P,
+                                           ldp, alpha, nti, ntj, part));
   BGP_HIP(h, hipGetLastError());
-  hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(1024), 0, st, part, nb, out);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(1024), 0, st, part, nb, out, accumulate);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

@@ -89,6 +89,8 @@ struct bgp_handle {
   bool has_data = false;     // X, y were uploaded through THIS life of the handle (a revived pooled handle starts without)
   bool t_sorted = false;     // column 0 of the resident X is ascending (checked on the device at upload)
   bool alpha_ready = false;
+  bool factor_consumed = false;  // bgp_lml_grad has overwritten L with Sigma^-1 in place: the next call that needs the factor
+                                 // re-runs the fit on the resident data first (ensure_factor)
   double jitter_used = 0.0, lml = 0.0;
   // device buffers
   double* dX = nullptr;      // [N, D] row-major
@@ -97,9 +99,6 @@ struct bgp_handle {
   double* dInv = nullptr;    // [Npad/64][64*64] inverses of the diagonal tiles of L
   double* dz = nullptr;      // [Npad] z = L^-1 y (zero in the padding)
   double* dalpha = nullptr;  // [Npad]
-  double* dB = nullptr;      // gradient workspace [B_ld, B_n]: U = L^-T (upper), overwritten in place by the upper triangle of
-                             // Sigma^-1 = U U^T; allocated on first bgp_lml_grad
-  int64_t B_ld = 0, B_n = 0;
   double* dLinvAll = nullptr;  // inv(L_pp) of every outer panel [npanels][nbL * nbL]: later query blocks (predict after fit)
   int64_t LinvAll_cap = 0;
   int64_t LinvAll_nb = 0;      // panel width they were built for; 0 = not valid for the current factor
@@ -186,10 +185,14 @@ int launch_norm2(bgp_handle* h, hipStream_t st, const double* a, const double* b
 int launch_copy_strided(bgp_handle* h, hipStream_t st, const double* src, int64_t n, double* dst,
                         int64_t ld_dst, int64_t npad);  // dst[i*ld_dst] = src[i] (i<n) else 0
 int grad_nacc();
-int64_t grad_blocks(int64_t n);
-int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n,
-                       const double* S, int64_t lds_, const double* alpha, double* part, double* out);
+int64_t grad_blocks(int64_t nrows, int64_t ncols);
+// one lower trapezoid of P = Sigma^-1 that starts on the diagonal at r0 (a column slab / a sharded column panel)
+int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const double* x, int64_t n, int64_t r0,
+                       int64_t nrows, int64_t ncols, const double* P, int64_t ldp, const double* alpha, double* part,
+                       double* out, int accumulate);
 int launch_flag_store(bgp_handle* h, hipStream_t st, const int* info, double* slot);
 int launch_flag_merge(bgp_handle* h, hipStream_t st, int* info, const double* slot);
 int launch_check_sorted(bgp_handle* h, hipStream_t st, const double* x, int64_t n, int D, int* flag);  // *flag = 1 if a descent is found
-int launch_set_identity(bgp_handle* h, hipStream_t st, double* B, int64_t ld, int64_t n);
+// dst = scale * op(src[rows, cols]); trans: dst[c + r ldd]; tri: src entries with r < c count as zero
+int launch_block_copy(bgp_handle* h, hipStream_t st, const double* src, int64_t lds_, int64_t rows, int64_t cols, double* dst,
+                      int64_t ldd, int trans, double scale, int tri);

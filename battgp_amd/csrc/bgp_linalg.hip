@@ -1086,9 +1086,31 @@ __global__ __launch_bounds__(1024) void norm2_kernel(const double* __restrict__ 
   if (threadIdx.x == 0) out[0] = r0[0];
 }
 
-__global__ __launch_bounds__(256) void set_diag_one_kernel(double* __restrict__ B, int64_t ld, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) B[i + i * ld] = 1.0;
+// dst = scale * op(mask(src)) for a block src[rows, cols] (column-major, lds_):  TRANS: dst[c + r ldd] (the transposed
+// block [cols, rows]), else dst[r + c ldd];  tri: entries above the diagonal of src (r < c) are taken as ZERO - a
+// triangular block whose upper half holds whatever the factorisation left there.  64 x 64 tiles through LDS: both the
+// reads and the writes run down columns (coalesced).  HBM-bound helper of the in-place inverse (bgp_lml_grad): it moves
+// a row block of the slab-stored triangle into the [k][row] operand form of gemm_nt_kernel and back.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void block_copy_kernel(const double* __restrict__ src, int64_t lds_, int64_t rows, int64_t cols,
+                                                         double* __restrict__ dst, int64_t ldd, double scale, int tri) {
+  __shared__ double t[64][65];
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int64_t r = r0 + tx, c = c0 + cc;
+    double v = 0.0;
+    if (r < rows && c < cols && !(tri && r < c)) v = scale * src[r + c * lds_];
+    if (TRANS) t[cc][tx] = v;
+    else if (r < rows && c < cols) dst[r + c * ldd] = v;
+  }
+  if (TRANS) {
+    __syncthreads();
+    for (int rr = ty; rr < 64; rr += 4) {
+      const int64_t r = r0 + rr, c = c0 + tx;  // dst row index = c (contiguous), dst column = r
+      if (r < rows && c < cols) dst[c + r * ldd] = t[tx][rr];
+    }
+  }
 }
 
 // augmented block below the matrix: row 0 = y^T (zero in the padding), other rows zero
@@ -1417,9 +1439,16 @@ int launch_copy_strided(bgp_handle* h, hipStream_t st, const double* src, int64_
   return 0;
 }
 
-int launch_set_identity(bgp_handle* h, hipStream_t st, double* B, int64_t ld, int64_t n) {
-  BGP_HIP(h, hipMemsetAsync(B, 0, (size_t)ld * (size_t)n * sizeof(double), st));
-  hipLaunchKernelGGL(set_diag_one_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, ld, n);
+int launch_block_copy(bgp_handle* h, hipStream_t st, const double* src, int64_t lds_, int64_t rows, int64_t cols, double* dst,
+                      int64_t ldd, int trans, double scale, int tri) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const int64_t gx = (rows + 63) / 64, gy = (cols + 63) / 64;
+  if (gx > 0x7fffffffLL || gy > 65535) return bgp_fail(h, -1, "block_copy: grid too large (%lld x %lld tiles)", (long long)gx, (long long)gy);
+  const dim3 grid((unsigned)gx, (unsigned)gy);
+  if (trans)
+    hipLaunchKernelGGL((block_copy_kernel<true>), grid, dim3(256), 0, st, src, lds_, rows, cols, dst, ldd, scale, tri);
+  else
+    hipLaunchKernelGGL((block_copy_kernel<false>), grid, dim3(256), 0, st, src, lds_, rows, cols, dst, ldd, scale, tri);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }

@@ -581,6 +581,7 @@ def main() -> None:
     ap.add_argument("--sharded-n", type=int, default=98304, help="size of the ONE sharded GP appended to a multi-GPU cells run (0 = skip)")
     ap.add_argument("--sharded-nb", type=int, default=1024)
     ap.add_argument("--sharded-steps", type=int, default=1)
+    ap.add_argument("--sharded-limit-s", type=float, default=900.0, help="time limit of the sharded sub-run of a multi-GPU cells run")
     ap.add_argument("--force-group", action="store_true",
                     help="build the process group even for ONE process, so that --mode sharded on a 1-GPU box sends every "
                          "broadcast / all-reduce of the schedule through RCCL (single-rank proxy with the collectives in)")
@@ -603,6 +604,7 @@ def main() -> None:
     dist = parallel.init(args.backend, device=torch.device("cuda", local_rank))  # nccl = RCCL; None for 1 process
     red_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
+    hung, sh = False, None
     if args.mode == "sharded":
         rec = run_sharded(args, rank, world, local_rank, args.n)
         if rank == 0:
@@ -620,7 +622,9 @@ def main() -> None:
         out = run_cells(args, rank, world, local_rank, dist, red_dev)
         sh = None
         if world > 1 and args.sharded_n > 0:
-            sh = run_sharded(args, rank, world, local_rank, args.sharded_n)
+            # the cells record above is complete; whatever the sharded sub-run does on ANY rank (an exception, a collective
+            # that never returns) must not cost the JSON line: it runs under a time limit and its failure is a field
+            sh, hung = _guarded(lambda: run_sharded(args, rank, world, local_rank, args.sharded_n), args.sharded_limit_s, local_rank)
         if rank == 0:
             if sh is not None:
                 out["sharded"] = sh
@@ -633,8 +637,39 @@ def main() -> None:
                 out["cpu_baseline"] = None
             print(json.dumps(out), flush=True)
     if dist is not None:
+        if hung or (isinstance(sh, dict) and "error" in sh):
+            # a rank of the group is stuck or gone: the tear-down collectives would wait for it - the line is out, leave
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _guarded(fn, limit_s: float, local_rank: int):
+    """Run ``fn`` in a worker thread for at most ``limit_s`` seconds.  Returns ``(result, hung)``; a failure or a timeout
+    comes back as ``{"error": ...}`` instead of propagating (a hung HIP / RCCL call can not be interrupted: the worker is
+    a daemon thread and the caller leaves with ``os._exit`` once its record is printed)."""
+    import threading
+
+    box = {}
+
+    def body():
+        try:
+            import torch
+
+            torch.cuda.set_device(local_rank)  # the current device is per thread
+            box["rec"] = fn()
+        except BaseException as exc:  # noqa: BLE001 - reported in the record
+            box["err"] = f"{type(exc).__name__}: {exc}"[:400]
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(limit_s)
+    if th.is_alive():
+        return {"error": f"no result within {limit_s:.0f} s (sub-run abandoned, cells record kept)"}, True
+    if "err" in box:
+        return {"error": box["err"]}, False
+    return box["rec"], False
 
 
 if __name__ == "__main__":

@@ -167,10 +167,15 @@ int bgp_fit_predict_dev(bgp_handle* h, const double* X_dev, const double* y_dev,
 
 /* Gradient of the LML of the last fit w.r.t. the hyper-parameter vector (same layout as hyp):
  *   d lml / d theta_i = 1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta_i).
- * Sigma^-1 is formed explicitly on the GPU (U = L^-T, then U U^T in place over U: 2/3 N^3 flop on the MFMA kernel,
- * ONE extra N^2 buffer kept on the handle), followed by one fused pass over its upper triangle that re-evaluates the
- * kernel derivatives.  Replaces the autograd backward of src/gp/training.py:41 (loss.backward()) up to the
- * factor -1/N and the raw-parameter chain rule, which stay on the host. */
+ * Sigma^-1 is formed explicitly on the GPU, IN PLACE over the Cholesky factor - M = L^-1 by a right-looking blocked
+ * inversion, then Sigma^-1 = M^T M by a blocked product, 2/3 N^3 flop that run as rank-nb updates on the same MFMA
+ * kernel as the factorisation's trailing update - followed by one fused pass over its lower triangle that
+ * re-evaluates the kernel derivatives.  No second N^2 buffer, in either layout (full square / column slabs):
+ * training reaches the same N as inference.  The factor is consumed; the next call that needs it (bgp_predict*,
+ * bgp_residuals, bgp_get_factor_*, another bgp_lml_grad at the same point) first re-runs the fit on the resident data
+ * - bit-identical factor, LML and alpha - so the handle stays usable like before; the optimiser loops re-fit with new
+ * hyper-parameters before every gradient anyway.  Replaces the autograd backward of src/gp/training.py:41
+ * (loss.backward()) up to the factor -1/N and the raw-parameter chain rule, which stay on the host. */
 int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad);
 
 /* PREDICT: posterior of the latent f at Xq[M,D] (no noise added):

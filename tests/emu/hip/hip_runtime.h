@@ -207,6 +207,7 @@ static inline hipError_t hipEventSynchronize(hipEvent_t e) {
   ::hipemu::event_sync(e);
   return hipSuccess;
 }
+static inline hipError_t hipEventQuery(hipEvent_t e) { return ::hipemu::event_done(e) ? hipSuccess : hipErrorNotReady; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   if (!::hipemu::event_done(a) || !::hipemu::event_done(b)) return hipErrorNotReady;  // like the real call
   *ms = (float)(b->t_ms - a->t_ms);

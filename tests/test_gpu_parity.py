@@ -344,14 +344,26 @@ def test_lml_gradient_matches_oracle(kid, n):
     lml_ref, g_ref = lml_and_grad(kid, hyp, x, y)
     e = ExactGPEngine(kid, hyp)
     lml = e.fit(x, y)
+    m0, v0 = e.predict(x[:5] + 0.01, min_var=-1.0)
+    d0 = e.factor_diag()
+    bytes0 = e.device_bytes()
     g = e.lml_grad()
+    bytes1 = e.device_bytes()
     g2 = e.lml_grad()  # workspaces are reused; result is run-to-run identical
-    m, v = e.predict(x[:5])  # the fit is still usable after the gradient
+    # the gradient forms Sigma^-1 IN PLACE over the factor; the next call that needs L gets it back bit for bit
+    m, v = e.predict(x[:5] + 0.01, min_var=-1.0)
+    d1 = e.factor_diag()
+    alpha = e.alpha()
     e.close()
     assert abs(lml - lml_ref) < 1e-9 * abs(lml_ref)
     assert np.allclose(g, g_ref, rtol=1e-7, atol=1e-9 * np.abs(g_ref).max()), (g, g_ref)
     assert np.array_equal(g, g2)
-    assert np.all(np.isfinite(m)) and np.all(v > 0)
+    assert np.array_equal(m, m0) and np.array_equal(v, v0) and np.array_equal(d0, d1)
+    ref = OracleGP(kid, hyp, x, y).fit()
+    assert np.linalg.norm(alpha - ref.alpha) < 1e-8 * np.linalg.norm(ref.alpha)
+    # no second N^2 buffer: only panel-sized workspaces may have been added (two transposed row blocks + the panel inverses)
+    npad = -(-n // 64) * 64
+    assert bytes1 - bytes0 <= 8 * (4 * (npad + 64) * 512 + 4 * 512 * 512) + 4096, (bytes0, bytes1)
 
 
 def test_lml_gradient_production_hyperparameters():
