@@ -86,6 +86,19 @@ SIGNATURES = {
     "bgp_flag_merge_dev": (C.c_int, [handle_p, C.c_void_p]),
     "bgp_flag_read": (C.c_int, [handle_p, c_int_p]),
     "bgp_get_stream": (C.c_void_p, [handle_p, C.c_int]),
+    "bgp_gemm_nt_async_dev": (
+        C.c_int,
+        [handle_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int],
+    ),
+    "bgp_block_copy_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_int]),
+    "bgp_panel_inverse_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "bgp_gemv_t_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "bgp_grad_nacc": (C.c_int, []),
+    "bgp_grad_reduce_block_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int],
+    ),
+    "bgp_grad_finish": (C.c_int, [handle_p, c_double_p, C.c_int, c_double_p, C.c_int]),
     "bgp_diag_logsum_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
     "bgp_rowdot_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "bgp_var_finish_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double, C.c_void_p]),

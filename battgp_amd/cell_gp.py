@@ -441,27 +441,14 @@ class BatteryCellGP:
         return -self.fit() / self._train_targets.shape[0]
 
     def neg_mll_and_raw_grad(self):
-        """``(loss, d loss / d raw)`` with ``loss = -lml / N``: the LML gradient comes from the GPU
-        (``bgp_lml_grad``), the raw-parameter chain rule (sigmoid / softplus) is applied here - together
-        what ``loss.backward()`` yields in ``src/gp/training.py:41``.  A sharded (``n_devices > 1``) model has no
-        analytic gradient pass: central differences of its LML in raw space (2 re-fits per parameter)."""
+        """``(loss, d loss / d raw)`` with ``loss = -lml / N``: the LML gradient comes from the GPU(s) - ``bgp_lml_grad``,
+        or ``ShardedExactGP.lml_grad`` for an ``n_devices > 1`` model (the same analytic
+        ``1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta)`` over the ranks' panels + one all-reduce) - and the
+        raw-parameter chain rule (sigmoid / softplus) is applied here: together what ``loss.backward()`` yields in
+        ``src/gp/training.py:41``."""
         n = self._train_targets.shape[0]
-        if self.n_devices > 1:
-            raw = self.raw_vector()
-            g = np.zeros_like(raw)
-            for i in range(raw.size):
-                h = 1e-4 * max(1.0, abs(raw[i]))
-                rp, rm = raw.copy(), raw.copy()
-                rp[i] += h
-                rm[i] -= h
-                self.set_raw_vector(rp)
-                fp = self.neg_mll()
-                self.set_raw_vector(rm)
-                g[i] = (fp - self.neg_mll()) / (2.0 * h)
-            self.set_raw_vector(raw)
-            return self.neg_mll(), g
         lml = self.fit()
-        g_hyp = self.engine().lml_grad()
+        g_hyp = self._shard().lml_grad() if self.n_devices > 1 else self.engine().lml_grad()
         return -lml / n, -(g_hyp * self.dvalue_draw()) / n
 
     def close(self):

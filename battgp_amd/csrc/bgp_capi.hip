@@ -1850,8 +1850,7 @@ int bgp_sync(bgp_handle* h) {
 }
 
 // accumulators of the reduction pass (grad_reduce_kernel) -> d lml / d theta in the hyper-parameter layout
-static void grad_from_acc(const bgp_handle* h, const double* a, double* grad_out, int ngrad) {
-  const int D = h->D;
+static void grad_from_acc(const bgp_handle* h, int D, const double* a, double* grad_out, int ngrad) {
   for (int i = 0; i < ngrad; ++i) grad_out[i] = 0.0;
   grad_out[0] = 0.5 * a[0];
   switch (h->kernel_id) {
@@ -1985,7 +1984,74 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   }
   BGP_HIP(h, hipMemcpyAsync(h->hscal, h->dscal, nacc * sizeof(double), hipMemcpyDeviceToHost, st));
   if ((rc = t.stop())) return rc;
-  grad_from_acc(h, h->hscal, grad_out, ngrad);
+  grad_from_acc(h, h->D, h->hscal, grad_out, ngrad);
+  return 0;
+}
+
+int bgp_gemm_nt_async_dev(bgp_handle* h, int mode, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                          const double* B_dev, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower, int btri) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!C_dev || !A_dev || !B_dev || mode < 0 || mode > 3) return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: bad arguments (mode=%d)", mode);
+  if (btri && mode != 1) return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: btri needs mode 1");
+  return launch_gemm_nt(h, h->s_main, mode, mode == 1 ? 64 : 128, C_dev, ldc, A_dev, lda, B_dev, ldb, m, n, k, lower, nullptr, btri);
+}
+
+int bgp_block_copy_dev(bgp_handle* h, const double* src_dev, int64_t lds, int64_t rows, int64_t cols, double* dst_dev,
+                       int64_t ldd, int trans, double scale, int tri) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!src_dev || !dst_dev || rows < 0 || cols < 0) return bgp_fail(h, -1, "bgp_block_copy_dev: bad arguments");
+  if (trans && src_dev == dst_dev) return bgp_fail(h, -1, "bgp_block_copy_dev: a transposition can not be in place");
+  return launch_block_copy(h, h->s_main, src_dev, lds, rows, cols, dst_dev, ldd, trans, scale, tri);
+}
+
+int bgp_panel_inverse_dev(bgp_handle* h, const double* panel_dev, int64_t ld, int nbk, const double* inv_dev, double* out_dev) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!panel_dev || !inv_dev || !out_dev || nbk < 64 || (nbk % 64) != 0 || nbk > 2048)
+    return bgp_fail(h, -1, "bgp_panel_inverse_dev: bad arguments (nbk=%d)", nbk);
+  // one "panel" of width nbk: the launcher's block forward substitution over its nbk/64 tiles
+  if ((rc = launch_trinv_panels(h, h->s_main, SlabView{const_cast<double*>(panel_dev), ld, BGP_W_FULL}, inv_dev, out_dev, nbk, nbk))) return rc;
+  return launch_block_copy(h, h->s_main, out_dev, nbk, nbk, nbk, out_dev, nbk, 0, 1.0, 1);
+}
+
+int bgp_gemv_t_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t rows, int ncols, const double* x_dev, double* out_dev) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!A_dev || !x_dev || !out_dev || rows < 1 || ncols < 64 || (ncols % 64) != 0)
+    return bgp_fail(h, -1, "bgp_gemv_t_dev: bad arguments (rows=%lld ncols=%d)", (long long)rows, ncols);
+  if ((rc = ensure_part(h, ((rows + 1023) / 1024 + 1) * (int64_t)ncols))) return rc;
+  int nch = 0;
+  if ((rc = launch_gemv_t_partial(h, h->s_main, A_dev, ld, x_dev, rows, ncols, h->dpart, &nch))) return rc;
+  FillParams p0;
+  memset(&p0, 0, sizeof(p0));
+  return launch_rowdot_finish(h, h->s_main, h->dpart, nch, ncols, nullptr, &p0, -1.0, out_dev);  // sum over the row chunks
+}
+
+int bgp_grad_nacc(void) { return grad_nacc(); }
+
+int bgp_grad_reduce_block_dev(bgp_handle* h, const double* X_dev, int64_t N, int D, int64_t r0, int64_t nrows, int64_t ncols,
+                              const double* P_dev, int64_t ldp, const double* alpha_dev, double* acc_dev, int accumulate) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!X_dev || !P_dev || !alpha_dev || !acc_dev || N < 1 || r0 < 0 || nrows < 1 || ncols < 1 || ncols > nrows)
+    return bgp_fail(h, -1, "bgp_grad_reduce_block_dev: bad arguments");
+  FillParams p;
+  if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
+  if (r0 >= N) {  // a block of the padding: nothing to add
+    if (!accumulate) BGP_HIP(h, hipMemsetAsync(acc_dev, 0, grad_nacc() * sizeof(double), h->s_main));
+    return 0;
+  }
+  if ((rc = ensure_part(h, grad_blocks(nrows, ncols) * grad_nacc()))) return rc;
+  return launch_grad_reduce(h, h->s_main, p, X_dev, N, r0, nrows, ncols, P_dev, ldp, alpha_dev, h->dpart, acc_dev, accumulate);
+}
+
+int bgp_grad_finish(bgp_handle* h, const double* acc_host, int D, double* grad_out, int ngrad) {
+  if (!h || !acc_host || !grad_out) return -1;
+  if (!h->kernel_set || ngrad != h->nhyp || expected_nhyp(h->kernel_id, D) != h->nhyp)
+    return bgp_fail(h, -1, "bgp_grad_finish: kernel %d with D=%d has %d hyper-parameters, got ngrad=%d", h->kernel_id, D, h->nhyp, ngrad);
+  grad_from_acc(h, D, acc_host, grad_out, ngrad);
   return 0;
 }
 

@@ -55,10 +55,13 @@ def kernel_setup(name: str):
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle = port of the reference algorithm; checker code timed as a baseline, never the product)
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline(kernel_name: str, n_cpu: int, m: int) -> dict:
-    """The oracle's dense algorithm on the host cores with its phases timed separately: threaded numpy fill,
-    LAPACK dpotrf (scipy), triangular solves + posterior.  `value` is the whole fit+predict; `potrf_gflops` is
-    LAPACK alone (what an honest "CPU Cholesky" figure means)."""
+def cpu_baseline(kernel_name: str, n_cpu: int, m: int, n_second: int = 0, budget_s: float = 150.0) -> dict:
+    """The oracle's dense algorithm on the host cores with its phases timed separately: threaded numpy fill, LAPACK
+    dpotrf, triangular solves + posterior.  The factorisation is timed with BOTH LAPACKs of this image - scipy's
+    OpenBLAS (built for at most 64 threads, whatever the host has) and torch's CPU LAPACK (MKL, `torch.get_num_threads()`
+    threads, no such cap) - and the faster one counts: `value` = algorithmic flop / (fill + best potrf + solves),
+    `cores` = the threads of that LAPACK.  `n_second` > 0 adds a second sample at that size (BASELINE configs[1]'s
+    N = 40 000) when the first sample's rate says it fits `budget_s`."""
     import scipy.linalg as sla
     from threadpoolctl import threadpool_info
 
@@ -66,16 +69,34 @@ def cpu_baseline(kernel_name: str, n_cpu: int, m: int) -> dict:
     from oracle import kernels as K
 
     kid, hyp, _ = kernel_setup(kernel_name)
+    blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    try:
+        import torch
 
-    def run(n):
+        torch_threads = int(torch.get_num_threads())
+    except Exception:  # noqa: BLE001
+        torch, torch_threads = None, 0
+
+    def run(n, both=True):
         x, y = synthetic.make_cell_data(n, seed=n)
         xq = synthetic.make_query(x, m)
         t0 = time.perf_counter()
         sigma = K.kernel_matrix_blocked(kid, hyp, x) if n > 2048 else K.kernel_matrix(kid, hyp, x)
         sigma[np.diag_indices(n)] += K.noise(hyp)
         t1 = time.perf_counter()
+        potrf = {}
+        if torch is not None and both:
+            try:
+                tt = time.perf_counter()
+                lt = torch.linalg.cholesky(torch.from_numpy(sigma))
+                potrf["torch_cpu_lapack"] = {"seconds": time.perf_counter() - tt, "threads": torch_threads}
+                del lt
+            except Exception as exc:  # noqa: BLE001 - the scipy path below is the one the solves use
+                potrf["torch_cpu_lapack"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        tt = time.perf_counter()
         chol, info = sla.lapack.dpotrf(sigma, lower=1, clean=0, overwrite_a=1)
         assert info == 0
+        potrf["scipy_openblas"] = {"seconds": time.perf_counter() - tt, "threads": int(blas_threads)}
         t2 = time.perf_counter()
         z = sla.solve_triangular(chol, y, lower=True, check_finite=False)
         kxs = K.kernel_matrix(kid, hyp, x, xq)
@@ -84,29 +105,48 @@ def cpu_baseline(kernel_name: str, n_cpu: int, m: int) -> dict:
         var = K.kernel_diag(kid, hyp, xq) - np.einsum("ij,ij->j", v, v)
         lml = -0.5 * float(z @ z) - float(np.sum(np.log(np.diag(chol)))) - 0.5 * n * np.log(2 * np.pi)
         t3 = time.perf_counter()
+        best = min((k for k in potrf if "seconds" in potrf[k]), key=lambda k: potrf[k]["seconds"])
+        potrf_s = potrf[best]["seconds"]
+        total = (t1 - t0) + potrf_s + (t3 - t2)
+        for k in potrf:
+            if "seconds" in potrf[k]:
+                potrf[k]["gflops"] = (n**3 / 3.0) / potrf[k]["seconds"] / 1e9
         return {
-            "n": n, "seconds": t3 - t0, "fill_s": t1 - t0, "potrf_s": t2 - t1, "solve_predict_s": t3 - t2,
-            "gflops": algorithmic_flop(n, m) / (t3 - t0) / 1e9, "potrf_gflops": (n**3 / 3.0) / (t2 - t1) / 1e9,
+            "n": n, "seconds": total, "fill_s": t1 - t0, "potrf_s": potrf_s, "solve_predict_s": t3 - t2,
+            "gflops": algorithmic_flop(n, m) / total / 1e9, "potrf_gflops": (n**3 / 3.0) / potrf_s / 1e9,
+            "potrf_by_lapack": potrf, "potrf_lapack_used": best, "threads": potrf[best]["threads"],
             "lml": lml, "mean0": float(mean[0]), "var0": float(var[0]),
         }
 
     main = run(n_cpu)
     cfg0 = run(2048)  # BASELINE configs[0]: the reference's own CPU-runnable case
-    blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-    return {
+    rec = {
         "value": main["gflops"],
         "unit": "GFLOP/s",
-        "cores": int(blas_threads),
+        "cores": int(main["threads"]),
         "host_cpus": os.cpu_count(),
         "fill_threads": min(32, os.cpu_count() or 1),
         "kind": "port",
         "seconds": main["seconds"],
         "phases": {k: main[k] for k in ("fill_s", "potrf_s", "solve_predict_s")},
         "potrf_gflops_lapack_alone": main["potrf_gflops"],
+        "potrf_by_lapack": main["potrf_by_lapack"],
         "config0_n2048": cfg0,
         "sample": f"same workload ({kernel_name}) at N={n_cpu}, one fit+predict with M={m}: oracle algorithm = numpy fill on "
-                  f"{min(32, os.cpu_count() or 1)} threads + LAPACK dpotrf/dtrtrs (scipy/OpenBLAS, {blas_threads} BLAS threads)",
+                  f"{min(32, os.cpu_count() or 1)} threads + LAPACK dpotrf/dtrtrs; dpotrf timed with scipy/OpenBLAS ({blas_threads} threads: "
+                  f"its build-time cap, host has {os.cpu_count()} CPUs) and torch CPU LAPACK ({torch_threads} threads), faster one counted "
+                  f"({main['potrf_lapack_used']})",
     }
+    if n_second > n_cpu:
+        est = main["seconds"] * (n_second / n_cpu) ** 3 * (2.0 if len(main["potrf_by_lapack"]) > 1 else 1.0)
+        if est <= budget_s:
+            try:
+                rec["second_sample"] = run(n_second)
+            except Exception as exc:  # noqa: BLE001
+                rec["second_sample"] = {"n": n_second, "error": f"{type(exc).__name__}: {exc}"[:200]}
+        else:
+            rec["second_sample"] = {"n": n_second, "skipped": f"estimated {est:.0f} s from the N={n_cpu} rate, budget {budget_s:.0f} s"}
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -534,7 +574,17 @@ def run_sharded(args, rank, world, local_rank, n):
         mean, var = gp.predict(xq)
     parallel.barrier(gp.dist)
     torch.cuda.synchronize()
-    dt = parallel.max_over_ranks(gp.dist, time.perf_counter() - t0, device=gp.be.device if args.backend == "nccl" else "cpu") / steps
+    red = gp.be.device if args.backend == "nccl" else "cpu"
+    dt = parallel.max_over_ranks(gp.dist, time.perf_counter() - t0, device=red) / steps
+    grad_s, grad = None, None
+    if args.sharded_grad:  # one optimiser iteration's second half: the analytic gradient (Sigma^-1 in place over the panels)
+        parallel.barrier(gp.dist)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        grad = gp.lml_grad()
+        parallel.barrier(gp.dist)
+        torch.cuda.synchronize()
+        grad_s = parallel.max_over_ranks(gp.dist, time.perf_counter() - t0, device=red)
     rec = None
     if rank == 0:
         flop = algorithmic_flop(n, args.m)
@@ -546,6 +596,9 @@ def run_sharded(args, rank, world, local_rank, n):
             "timers_s": gp.timers(), "lml": lml, "jitter": gp.jitter, "mean_first": [float(v) for v in mean[:3]],
             "var_first": [float(v) for v in var[:3]], "scaling": "strong",
         }
+        if grad_s is not None:
+            rec["lml_grad"] = {"seconds": grad_s, "tflops_per_gpu": (2.0 * n**3 / 3.0) / grad_s / 1e12 / world,
+                               "over_one_fit_predict": grad_s / dt, "grad": [float(v) for v in grad]}
     gp.close()
     return rec
 
@@ -566,6 +619,8 @@ def main() -> None:
     ap.add_argument("--panel-scheme", type=int, default=-1, help="0 = 64-wide chain over all rows, 1 = diagonal-block chain + one deep TRSM GEMM (default)")
     ap.add_argument("--slab", type=int, default=0, help="bgp_set_layout: 0 automatic, -1 full square, > 0 column-slab width")
     ap.add_argument("--cpu-n", type=int, default=16384, help="size of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-n2", type=int, default=40000, help="second CPU-baseline sample (BASELINE configs[1]'s size), run only when the first sample's rate says it fits --cpu-budget-s (0 = never)")
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0)
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (steady fill, memset ceiling, N = 40 000 extra config)")
     ap.add_argument("--side-budget-s", type=float, default=480.0,
@@ -581,6 +636,7 @@ def main() -> None:
     ap.add_argument("--sharded-n", type=int, default=98304, help="size of the ONE sharded GP appended to a multi-GPU cells run (0 = skip)")
     ap.add_argument("--sharded-nb", type=int, default=1024)
     ap.add_argument("--sharded-steps", type=int, default=1)
+    ap.add_argument("--sharded-grad", action="store_true", help="also time ONE analytic LML gradient of the sharded GP (2/3 N^3 flop)")
     ap.add_argument("--sharded-limit-s", type=float, default=900.0, help="time limit of the sharded sub-run of a multi-GPU cells run")
     ap.add_argument("--force-group", action="store_true",
                     help="build the process group even for ONE process, so that --mode sharded on a 1-GPU box sends every "
@@ -630,7 +686,7 @@ def main() -> None:
                 out["sharded"] = sh
             if args.cpu_n > 0 and world == 1:
                 try:
-                    out["cpu_baseline"] = cpu_baseline(args.kernel, args.cpu_n, args.m)
+                    out["cpu_baseline"] = cpu_baseline(args.kernel, args.cpu_n, args.m, args.cpu_n2, args.cpu_budget_s)
                 except Exception as exc:  # noqa: BLE001 - the GPU record is printed whatever happens to the host-side sample
                     out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"[:300]}
             elif world > 1:

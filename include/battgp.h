@@ -313,6 +313,42 @@ int bgp_gemm_nt_sub_async_dev(bgp_handle* h, double* C_dev, int64_t ldc, const d
 int bgp_update_panels_dev(bgp_handle* h, double* store_dev, const int64_t* desc, int count, const double* P_dev,
                           int64_t ldp, int k, const double* abort_flag_dev);
 
+/* ---- building blocks of the sharded LML gradient: Sigma^-1 formed IN PLACE over the distributed factor
+ * (battgp_amd/sharded.py::ShardedExactGP.lml_grad; the single-GPU bgp_lml_grad runs the same steps on its slabs).
+ * All asynchronous on the handle's stream. ---- */
+
+/* General form of the MFMA product  C[m, n] (op)= A[m, k] B[n, k]^T  (all column-major; k a multiple of 16; m, n, lda,
+ * ldb even; A, B 16-byte aligned):  mode 0  C -= A B^T;  mode 1  C = A B^T (C must not overlap A or B unless n <= 64);
+ * mode 2  C -= A B^T accumulated by one L2 atomic per element (no C read; deep k);  mode 3  C += A B^T.
+ * lower != 0: only tiles touching i >= j.  btri != 0 (mode 1): B is lower triangular (B[j, kk] = 0 for kk > j) and
+ * the zero half of the k-range is skipped. */
+int bgp_gemm_nt_async_dev(bgp_handle* h, int mode, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                          const double* B_dev, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower, int btri);
+
+/* dst = scale * op(src[rows, cols]) (column-major): trans != 0 writes the transposed block dst[c + r ldd], else
+ * dst[r + c ldd]; tri != 0 takes the entries above the diagonal of src (r < c) as zero.  src == dst is allowed for
+ * trans == 0. */
+int bgp_block_copy_dev(bgp_handle* h, const double* src_dev, int64_t lds, int64_t rows, int64_t cols, double* dst_dev,
+                       int64_t ldd, int trans, double scale, int tri);
+
+/* out_dev[nbk, nbk] (ld = nbk, clean lower triangle, zeros above) = inv(L_kk) of a factored panel's diagonal block
+ * (panel_dev, ld) from its nbk/64 inverted diagonal tiles inv_dev (what bgp_factor_pack_panel_async_dev left). */
+int bgp_panel_inverse_dev(bgp_handle* h, const double* panel_dev, int64_t ld, int nbk, const double* inv_dev, double* out_dev);
+
+/* out_dev[c] = sum_{r < rows} A[r + c ld] x[r],  c < ncols (a multiple of 64): A^T x of a tall column block. */
+int bgp_gemv_t_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t rows, int ncols, const double* x_dev, double* out_dev);
+
+/* Number of accumulators of the gradient reduction, and the reduction over ONE lower trapezoid of P = Sigma^-1 that
+ * starts on the diagonal: rows [r0, r0 + nrows) x columns [r0, r0 + ncols) of the matrix, element (i, j) at
+ * P_dev[(i - r0) + (j - r0) ldp] (a column panel of the sharded store).  acc_dev[0 .. nacc) is increased by
+ * sum' (alpha_i alpha_j - P_ij) dSigma_ij/d(.) of that block (accumulate == 0: overwritten).  X_dev [N, D] row-major,
+ * alpha_dev [>= r0 + nrows].  bgp_grad_finish turns the (all-reduced) accumulators, copied to the host, into
+ * d lml / d theta in the layout of hyp - the same arithmetic as bgp_lml_grad. */
+int bgp_grad_nacc(void);
+int bgp_grad_reduce_block_dev(bgp_handle* h, const double* X_dev, int64_t N, int D, int64_t r0, int64_t nrows, int64_t ncols,
+                              const double* P_dev, int64_t ldp, const double* alpha_dev, double* acc_dev, int accumulate);
+int bgp_grad_finish(bgp_handle* h, const double* acc_host, int D, double* grad_out, int ngrad);
+
 /* out_host[0] = sum_{i<n} log A[i + i*ld] (half log-determinant of a factored diagonal block). Synchronous. */
 int bgp_diag_logsum_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t n, double* out_host);
 

@@ -137,6 +137,41 @@ class OracleGP:
         return float(r1), float(r2)
 
 
+def kernel_derivatives(kernel_id: int, hyp, x1: np.ndarray, x2: np.ndarray) -> list[np.ndarray]:
+    """``[dK(x1, x2)/d hyp_i for i = 1 .. len(hyp) - 1]`` (the noise term, i = 0, is the identity on the training
+    diagonal and is left to the caller) - the kernel derivatives autograd differentiates through at
+    ``src/gp/training.py:41``; block form so that a distributed reduction can be checked panel by panel."""
+    hyp = np.asarray(hyp, dtype=np.float64)
+    x1 = np.atleast_2d(np.asarray(x1, dtype=np.float64))
+    x2 = np.atleast_2d(np.asarray(x2, dtype=np.float64))
+    d = x1.shape[1]
+
+    def sq(col, ls_d):
+        diff = (x1[:, col : col + 1] - x2[:, col : col + 1].T) / ls_d
+        return diff * diff
+
+    if kernel_id == K.KERNEL_BATTGP:
+        s_r, ls = hyp[2], hyp[3:]
+        e = np.exp(-0.5 * K._scaled_sqdist(x1[:, 1:], x2[:, 1:], ls))
+        return [K.integrated_wiener(x1[:, 0], x2[:, 0]), e] + [s_r * e * sq(1 + dd, ls[dd]) / ls[dd] for dd in range(d - 1)]
+    if kernel_id == K.KERNEL_SCALED_RBF:
+        s, ell = hyp[1], hyp[2]
+        q = K._scaled_sqdist(x1, x2, np.full(d, ell))
+        e = np.exp(-0.5 * q)
+        return [e, s * e * q / ell]
+    if kernel_id == K.KERNEL_ARD_RBF:
+        s, ls = hyp[1], hyp[2:]
+        e = np.exp(-0.5 * K._scaled_sqdist(x1, x2, ls))
+        return [e] + [s * e * sq(dd, ls[dd]) / ls[dd] for dd in range(d)]
+    if kernel_id == K.KERNEL_MATERN32:
+        s, ls = hyp[1], hyp[2:]
+        a = np.sqrt(3.0) * np.sqrt(K._scaled_sqdist(x1, x2, ls))
+        ea = np.exp(-a)
+        # dk/dl_d = s * 3 * exp(-a) * ((x_d-x'_d)/l_d)^2 / l_d
+        return [(1.0 + a) * ea] + [s * 3.0 * ea * sq(dd, ls[dd]) / ls[dd] for dd in range(d)]
+    raise ValueError(f"unknown kernel id {kernel_id}")
+
+
 def lml_and_grad(kernel_id: int, hyp, x: np.ndarray, y: np.ndarray):
     """LML and its gradient w.r.t. the hyper-parameter vector (same layout as
     ``hyp``):  ``d lml / d theta = 1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta)``.
@@ -148,48 +183,11 @@ def lml_and_grad(kernel_id: int, hyp, x: np.ndarray, y: np.ndarray):
     hyp = np.asarray(hyp, dtype=np.float64)
     gp = OracleGP(kernel_id, hyp, x, y).fit()
     xx = gp.x
-    n, d = xx.shape
+    n = xx.shape[0]
     linv = sla.solve_triangular(gp.L, np.eye(n), lower=True)
     w = np.outer(gp.alpha, gp.alpha) - linv.T @ linv  # alpha alpha^T - Sigma^-1
     grad = np.zeros_like(hyp)
     grad[0] = 0.5 * np.trace(w)  # dSigma/dnoise = I
-
-    def sq(cols, ls_d, dd):
-        diff = (xx[:, cols[dd] : cols[dd] + 1] - xx[:, cols[dd] : cols[dd] + 1].T) / ls_d
-        return diff * diff
-
-    if kernel_id == K.KERNEL_BATTGP:
-        s_w, s_r, ls = hyp[1], hyp[2], hyp[3:]
-        kw = K.integrated_wiener(xx[:, 0], xx[:, 0])
-        e = np.exp(-0.5 * K._scaled_sqdist(xx[:, 1:], xx[:, 1:], ls))
-        grad[1] = 0.5 * np.sum(w * kw)
-        grad[2] = 0.5 * np.sum(w * e)
-        cols = list(range(1, d))
-        for dd in range(d - 1):
-            grad[3 + dd] = 0.5 * np.sum(w * (s_r * e * sq(cols, ls[dd], dd) / ls[dd]))
-    elif kernel_id == K.KERNEL_SCALED_RBF:
-        s, ell = hyp[1], hyp[2]
-        q = K._scaled_sqdist(xx, xx, np.full(d, ell))
-        e = np.exp(-0.5 * q)
-        grad[1] = 0.5 * np.sum(w * e)
-        grad[2] = 0.5 * np.sum(w * (s * e * q / ell))
-    elif kernel_id == K.KERNEL_ARD_RBF:
-        s, ls = hyp[1], hyp[2:]
-        e = np.exp(-0.5 * K._scaled_sqdist(xx, xx, ls))
-        grad[1] = 0.5 * np.sum(w * e)
-        cols = list(range(d))
-        for dd in range(d):
-            grad[2 + dd] = 0.5 * np.sum(w * (s * e * sq(cols, ls[dd], dd) / ls[dd]))
-    elif kernel_id == K.KERNEL_MATERN32:
-        s, ls = hyp[1], hyp[2:]
-        r = np.sqrt(K._scaled_sqdist(xx, xx, ls))
-        a = np.sqrt(3.0) * r
-        ea = np.exp(-a)
-        grad[1] = 0.5 * np.sum(w * ((1.0 + a) * ea))
-        cols = list(range(d))
-        for dd in range(d):
-            # dk/dl_d = s * 3 * exp(-a) * ((x_d-x'_d)/l_d)^2 / l_d
-            grad[2 + dd] = 0.5 * np.sum(w * (s * 3.0 * ea * sq(cols, ls[dd], dd) / ls[dd]))
-    else:
-        raise ValueError(f"unknown kernel id {kernel_id}")
+    for i, dk in enumerate(kernel_derivatives(kernel_id, hyp, xx, xx)):
+        grad[1 + i] = 0.5 * np.sum(w * dk)
     return gp.lml, grad

@@ -68,6 +68,10 @@ def main() -> int:
             lml = gp.fit(x, y)
             mean, var = gp.predict(synthetic.make_query(x, 37))
             assert np.isfinite(lml) and np.all(np.isfinite(mean)) and np.all(var > 0)
+            g = gp.lml_grad()  # Sigma^-1 in place over the panels: block copies, the general GEMM entry, panel inverse, gemv_t, reduction
+            assert np.all(np.isfinite(g))
+            mean2, _ = gp.predict(synthetic.make_query(x, 37))  # the factor comes back
+            assert np.array_equal(mean, mean2)
             gp.close()
     print("ASAN-PASS-DONE")
     return 0

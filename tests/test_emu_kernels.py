@@ -3,7 +3,7 @@ stand-in <hip/hip_runtime.h> whose workgroups run as cooperative fibers (barrier
 16x16x4 MFMA with the gfx950 lane layout).  These tests run a selection of the ``-m gpu`` parity tests - the very same
 test functions, imported from their modules - through that build, at sizes a CPU finishes in seconds: the kernels'
 indexing and algebra (fill, tile Cholesky, MFMA GEMM modes, panel schemes, look-ahead, slab layout, triangular solves,
-LAUUM gradient, jitter ladder) are checked against the oracle in the ``-m "not gpu"`` suite as well.
+in-place inverse gradient, jitter ladder) are checked against the oracle in the ``-m "not gpu"`` suite as well.
 
 Test infrastructure only: it proves nothing about speed or about what the GPU executes (that is what ``-m gpu`` is for),
 the product binding cannot reach this library, and nothing here is ever timed or shipped.
@@ -103,7 +103,7 @@ def test_lml_gradient_vs_oracle(P, kid):
 
 def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
     """Several outer panels at a CPU-sized N (nb_outer = 128, N = 600): panel schemes 0 and 1, look-ahead off / depth 1 /
-    depth 2 / ordered, the column-slab layout, the LAUUM gradient and the explicit-inverse backward solve - the code
+    depth 2 / ordered, the column-slab layout, the in-place inverse gradient and the explicit-inverse backward solve - the code
     paths the GPU only reaches from N = 16 384 on with the default widths."""
     from battgp_amd import synthetic
     from battgp_amd.engine import ExactGPEngine
@@ -241,7 +241,8 @@ def test_stream_graph_under_adversarial_schedules(emu):
 def test_sharded_device_backend_ranks_on_the_cpu_build(world, sched):
     """tests/test_gpu_sharded.py's multi-rank worker (DeviceBackend: the engine's per-panel C-ABI building blocks driven
     by sharded.py, gloo between the ranks) with every rank on the CPU build and its streams deferred (HIPEMU_SCHED): the
-    packing, offsets, look-ahead exchange and stream hand-offs of the multi-GPU schedule against the oracle, without a GPU"""
+    packing, offsets, look-ahead exchange and stream hand-offs of the multi-GPU schedule (factorisation, prediction pass and
+    the distributed in-place inverse of the gradient) against the oracle, without a GPU"""
     import socket
 
     import torch.multiprocessing as mp
@@ -280,10 +281,15 @@ def test_sharded_device_backend_ranks_on_the_cpu_build(world, sched):
     xq = synthetic.make_query(x, 33)
     ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
     m_ref, v_ref = ref.predict(xq)
-    for rank, lml, mean, var in res:
+    from oracle.exact_gp import lml_and_grad
+
+    _, g_ref = lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)
+    for rank, lml, mean, var, grad in res:
         assert abs(lml - ref.lml) < 1e-6 * abs(ref.lml)
         assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
         assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+        # the analytic gradient of the sharded model: Sigma^-1 in place over the ranks' panels, exchanges one step ahead
+        assert np.allclose(np.array(grad), g_ref, rtol=1e-5), (rank, grad, g_ref)
     assert all(r[1:] == res[0][1:] for r in res)
 
 

@@ -31,14 +31,24 @@ def test_sharded_single_rank_matches_oracle_and_engine(n, nb):
     assert np.max(np.abs(var - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
     e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
     assert abs(e.fit(x, y) - lml) < 1e-9 * abs(lml)
+    g_eng = e.lml_grad()
     e.close()
+    # analytic LML gradient: Sigma^-1 in place over the panels (consumes the factor), then predictions as before
+    from oracle.exact_gp import lml_and_grad
+
+    _, g_ref = lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)
+    grad = gp.lml_grad()
+    assert np.allclose(grad, g_ref, rtol=1e-5), (grad, g_ref)
+    assert np.allclose(grad, g_eng, rtol=1e-6), (grad, g_eng)
+    mean_b, var_b = gp.predict(xq)
+    assert np.array_equal(mean_b, mean) and np.array_equal(var_b, var)
     # a second fit on the same object (resident buffers, new hyper-parameters) and the timers
     hyp2 = synthetic.HYP_BATTGP.copy()
     hyp2[2] *= 2.0
     gp.set_hyp(hyp2)
     lml2 = gp.fit(x, y)
     assert abs(lml2 - OracleGP(K.KERNEL_BATTGP, hyp2, x, y).fit().lml) < 1e-6 * abs(lml2)
-    assert set(gp.timers()) == {"fit_s", "predict_s"}
+    assert set(gp.timers()) == {"fit_s", "predict_s", "grad_s"}
     gp.close()
 
 
@@ -67,6 +77,20 @@ def test_sharded_matern_and_jitter():
     gp.close()
 
 
+def _emu_hook(root):
+    """tests/test_emu_kernels.py / `pytest --emu` with BGP_TEST_EMU=1: the spawned ranks run on the CPU build of the kernel
+    sources (test infrastructure; the "device" buffers are host memory, the streams follow HIPEMU_SCHED)"""
+    import os
+    import sys
+
+    if os.environ.get("BGP_TEST_EMU") == "1":
+        sys.path.insert(0, os.path.join(root, "tests", "emu"))
+        from inject import fake_cuda_tensors, installed
+
+        fake_cuda_tensors()
+        installed().__enter__()
+
+
 def _two_rank_worker(rank, world, port, n, nb, q):
     import os
     import sys
@@ -76,14 +100,7 @@ def _two_rank_worker(rank, world, port, n, nb, q):
     # both ranks share the one GPU of the test box; gloo moves the device buffers (RCCL refuses two ranks
     # on one device) - the schedule, packing and offsets are exactly those of the multi-GPU run
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    if os.environ.get("BGP_TEST_EMU") == "1":
-        # tests/test_emu_kernels.py: the same ranks on the CPU build of the kernel sources (test infrastructure; the
-        # "device" buffers are host memory, the streams follow HIPEMU_SCHED)
-        sys.path.insert(0, os.path.join(root, "tests", "emu"))
-        from inject import fake_cuda_tensors, installed
-
-        fake_cuda_tensors()
-        installed().__enter__()
+    _emu_hook(root)
     from battgp_amd import parallel, synthetic
     from battgp_amd.sharded import make_sharded_gp
 
@@ -92,7 +109,8 @@ def _two_rank_worker(rank, world, port, n, nb, q):
     gp = make_sharded_gp(0, synthetic.HYP_BATTGP, nb=nb, backend_name="gloo")
     lml = gp.fit(x, y)
     mean, var = gp.predict(xq)
-    q.put((rank, lml, mean.tolist(), var.tolist()))
+    grad = gp.lml_grad()
+    q.put((rank, lml, mean.tolist(), var.tolist(), grad.tolist()))
     parallel.barrier(gp.dist)
     dist = gp.dist
     gp.close()
@@ -122,10 +140,14 @@ def test_sharded_two_ranks_device_backend_over_gloo():
     xq = synthetic.make_query(x, 33)
     ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
     m_ref, v_ref = ref.predict(xq)
-    for rank, lml, mean, var in res:
+    from oracle.exact_gp import lml_and_grad
+
+    _, g_ref = lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)
+    for rank, lml, mean, var, grad in res:
         assert abs(lml - ref.lml) < 1e-6 * abs(ref.lml)
         assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
         assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+        assert np.allclose(np.array(grad), g_ref, rtol=1e-5), (rank, grad, g_ref)
     assert res[0][1:] == res[1][1:]
 
 
@@ -160,7 +182,8 @@ def _rccl_world1_worker(port, n, nb, q):
         assert gp.dist is not None and dist.get_backend() == "nccl"
         lml = gp.fit(x, y)
         mean, var = gp.predict(xq)
-        q.put(("ok", lml, mean.tolist(), var.tolist()))
+        grad = gp.lml_grad()  # its broadcasts / all-reduces (async, waited on the device) go through RCCL as well
+        q.put(("ok", lml, mean.tolist(), var.tolist(), grad.tolist()))
         gp.close()
         dist.destroy_process_group()
     except BaseException as exc:  # noqa: BLE001 - reported to the parent, which decides
@@ -192,7 +215,7 @@ def test_sharded_one_rank_group_over_rccl():
         pytest.skip(f"RCCL cannot run a one-rank group on this box ({res[1]}): environment, not the engine")
     assert res[0] == "ok", res
     assert p.exitcode == 0
-    _, lml, mean, var = res
+    _, lml, mean, var, grad = res
     x, y = synthetic.make_cell_data(n, seed=11)
     xq = synthetic.make_query(x, 33)
     ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
@@ -200,6 +223,9 @@ def test_sharded_one_rank_group_over_rccl():
     assert abs(lml - ref.lml) < 1e-6 * abs(ref.lml)
     assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
     assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+    from oracle.exact_gp import lml_and_grad
+
+    assert np.allclose(np.array(grad), lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)[1], rtol=1e-5)
 
 
 def _colmajor(a, ld=None):
@@ -304,6 +330,7 @@ def _plugin_worker(rank, world, port, n, q):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _emu_hook(root)
     import torch.distributed as dist
 
     from battgp_amd import synthetic
@@ -316,7 +343,14 @@ def _plugin_worker(rank, world, port, n, q):
     t = np.linspace(x[0, 0], x[-1, 0], 40)
     df = cell.predict_r0_op(Op(*synthetic.REF_OP), t)
     loss = cell.model.neg_mll() * n
-    q.put((rank, df["r0_acausal_c3"].tolist(), df["r0var_acausal_c3"].tolist(), loss))
+    loss2, raw_grad = cell.model.neg_mll_and_raw_grad()  # analytic, sharded: what loss.backward() gives the reference
+    assert loss2 * n == loss
+    # three optimiser iterations through the plugin (the reference's train_hyperparameters, battcellgp_full.py:127-166):
+    # every iteration = one sharded fit + one distributed in-place inverse
+    trained = BatteryCellGP_Full(x, y, cellnr=4, n_devices=world, device=0, max_iter=3)
+    losses = trained.train_hyperparameters(messages=False)
+    q.put((rank, df["r0_acausal_c3"].tolist(), df["r0var_acausal_c3"].tolist(), loss, raw_grad.tolist(), np.asarray(losses).tolist()))
+    del trained.model
     dist.barrier()
     del cell.model
     dist.destroy_process_group()
@@ -348,8 +382,18 @@ def test_plugin_n_devices_routes_to_the_sharded_engine():
     xq = np.column_stack((t, np.full(40, synthetic.REF_OP[0]), np.full(40, synthetic.REF_OP[1]), np.full(40, synthetic.REF_OP[2])))
     ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
     m_ref, v_ref = ref.predict(xq)
-    for rank, mean, var, loss in res:
+    # the same model on ONE device: loss and raw-parameter gradient of the single-GPU engine
+    from battgp_amd.battcellgp_full import BatteryCellGP_Full
+
+    one = BatteryCellGP_Full(x, y, cellnr=3, device=0, max_iter=3)
+    _, raw_one = one.model.neg_mll_and_raw_grad()
+    losses_one = np.asarray(one.train_hyperparameters(messages=False))
+    del one.model
+    for rank, mean, var, loss, raw_grad, losses in res:
+        # the optimiser walks the same path on two ranks as on one device
+        assert np.allclose(np.asarray(losses), losses_one, rtol=1e-7, equal_nan=True), (losses, losses_one)
         assert np.linalg.norm(np.array(mean) - m_ref) < 1e-6 * np.linalg.norm(m_ref)
         assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
         assert abs(loss - ref.neg_mll_scaled) < 1e-6 * abs(ref.neg_mll_scaled)
+        assert np.allclose(np.array(raw_grad), raw_one, rtol=1e-6, atol=1e-12 * np.abs(raw_one).max()), (raw_grad, raw_one)
     assert res[0][1:] == res[1][1:]

@@ -153,6 +153,68 @@ class NumpyBackend:
     def set_segment(self, vec, c0, seg):
         vec[c0 : c0 + seg.shape[0]] = seg
 
+    def fill_zero(self, buf, count):
+        buf[: int(count)] = 0.0
+
+    def allreduce_start(self, dist, t):
+        return dist.all_reduce(self._t(t), async_op=True)
+
+    # ---- gradient: the building blocks of ShardedExactGP.lml_grad ----
+    def gemm(self, mode, c, coff, ldc, a, aoff, lda, b, boff, ldb, m, n, k, lower=0, btri=0):
+        am, bm = self._cm(a, aoff, m, k, lda), self._cm(b, boff, n, k, ldb)
+        if btri:  # the caller promises a lower-triangular B: what lies above its diagonal must not matter
+            bm = np.tril(bm)
+        prod = am @ bm.T
+        cm = self._cm(c, coff, m, n, ldc)
+        if lower:  # only the part on or below the diagonal is defined (the kernel works at tile granularity)
+            keep = np.tril(np.ones((m, n), dtype=bool))
+            cm[keep] = (cm + prod)[keep] if mode == 3 else ((cm - prod)[keep] if mode in (0, 2) else prod[keep])
+        elif mode in (0, 2):
+            cm[:] -= prod
+        elif mode == 1:
+            cm[:] = prod
+        else:
+            cm[:] += prod
+
+    def block_copy(self, src, soff, lds, rows, cols, dst, doff, ldd, trans=0, scale=1.0, tri=0):
+        blk = scale * self._cm(src, soff, rows, cols, lds)
+        if tri:
+            blk = np.tril(blk)
+        if trans:
+            self._cm(dst, doff, cols, rows, ldd)[:] = blk.T
+        else:
+            self._cm(dst, doff, rows, cols, ldd)[:] = blk
+
+    def panel_inverse(self, store, off, ld, nbk, inv, out):
+        l11 = np.tril(self._cm(store, off, nbk, nbk, ld))
+        self._cm(out, 0, nbk, nbk, nbk)[:] = np.linalg.solve(l11, np.eye(nbk))
+
+    def gemv_t(self, a, aoff, ld, rows, ncols, x, xoff, out, ooff):
+        out[ooff : ooff + ncols] = self._cm(a, aoff, rows, ncols, ld).T @ x[xoff : xoff + rows]
+
+    def grad_acc(self):
+        return np.zeros(len(self.hyp))
+
+    def grad_reduce(self, x, n, d, r0, nrows, ncols, store, off, ld, alpha, acc):
+        """1/2 sum' (alpha_i alpha_j - P_ij) dSigma_ij/dtheta over the block's lower trapezoid (off-diagonal pairs count
+        twice), kernel derivatives from the ORACLE's block form"""
+        from oracle.exact_gp import kernel_derivatives
+
+        ri = np.arange(r0, min(r0 + nrows, n))
+        cj = np.arange(r0, min(r0 + ncols, n))
+        if ri.size == 0 or cj.size == 0:
+            return
+        p = self._cm(store, off, nrows, ncols, ld)[: ri.size, : cj.size]
+        w = np.outer(alpha[ri], alpha[cj]) - p
+        wgt = np.where(ri[:, None] > cj[None, :], 2.0, np.where(ri[:, None] == cj[None, :], 1.0, 0.0))
+        w = w * wgt
+        acc[0] += 0.5 * np.sum(w[ri[:, None] == cj[None, :]])
+        for i, dk in enumerate(kernel_derivatives(self.kid, self.hyp, x[ri], x[cj])):
+            acc[1 + i] += 0.5 * np.sum(w * dk)
+
+    def grad_finish(self, acc, d):
+        return np.array(acc)
+
 
 def _free_port():
     s = socket.socket()
@@ -176,7 +238,10 @@ def _worker(rank, world, port, n, nb, q):
     gp = ShardedExactGP(NumpyBackend(0, synthetic.HYP_BATTGP), dist, rank, world, nb=nb)
     lml = gp.fit(x, y)
     mean, var = gp.predict(xq)
-    q.put((rank, lml, mean.tolist(), var.tolist()))
+    grad = gp.lml_grad()            # consumes the factor (Sigma^-1 in place over the distributed panels) ...
+    mean2, var2 = gp.predict(xq)    # ... and the next prediction gets it back
+    assert np.array_equal(mean, mean2) and np.array_equal(var, var2)
+    q.put((rank, lml, mean.tolist(), var.tolist(), grad.tolist()))
     if dist is not None:
         parallel.barrier(dist)
         dist.destroy_process_group()
@@ -208,10 +273,16 @@ def test_sharded_gp_matches_oracle(world, n, nb):
     xq = synthetic.make_query(x, 21)
     ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y).fit()
     m_ref, v_ref = ref.predict(xq)
-    for rank, lml, mean, var in res:
+    from oracle.exact_gp import lml_and_grad
+
+    _, g_ref = lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)
+    for rank, lml, mean, var, grad in res:
         assert abs(lml - ref.lml) < 1e-9 * abs(ref.lml), (rank, lml, ref.lml)
         assert np.linalg.norm(np.array(mean) - m_ref) < 1e-8 * np.linalg.norm(m_ref)
         assert np.max(np.abs(np.array(var) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+        # the analytic gradient of the sharded model (the reference's ONE backward pass, src/gp/training.py:39-41);
+        # entries span 20 orders of magnitude: each relative to itself
+        assert np.allclose(np.array(grad), g_ref, rtol=1e-6), (rank, grad, g_ref)
     assert res[0][1:] == res[1][1:]  # every rank ends with identical results
 
 

@@ -6,7 +6,7 @@
 #       gpurun --timeout 3300 -- 'bash tools/gpu_session.sh r02 [stage ...]'
 # Everything lands under gpurun_out/<tag>s/ ; copy what is to be judged into profiles/ afterwards
 # (python tools/pmc_summary.py gpurun_out/<tag>s/pmc131k <tag> 131072 matern32).
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 STAGES=${*:-"tests bench stats pmc sweep slim system train fill sharded"}
 REPO=$(pwd); OUT=$REPO/gpurun_out/${TAG}s; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -68,8 +68,8 @@ if has fill; then
 fi
 if has sharded; then
   stamp "sharded driver, single-rank proxy"
-  timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras > $OUT/sharded_n65536.json 2> $OUT/sharded.err
-  timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras --force-group > $OUT/sharded_n65536_rccl.json 2>> $OUT/sharded.err
+  timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras --sharded-grad > $OUT/sharded_n65536.json 2> $OUT/sharded.err
+  timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras --sharded-grad --force-group > $OUT/sharded_n65536_rccl.json 2>> $OUT/sharded.err
   timeout 900 python bench.py --mode sharded --n 131072 --kernel battgp --steps 1 --warmup 0 --cpu-n 0 --no-extras > $OUT/sharded_n131072.json 2>> $OUT/sharded.err
 fi
 stamp done
