@@ -58,6 +58,8 @@ fi
 if has train; then
   stamp "optimiser iteration (LML + gradient)"
   timeout 600 python tools/train_iter.py 1000 4000 16000 40000 > $OUT/train_iter.jsonl 2> $OUT/train_iter.err
+  # the in-place-inverse gradient where the second N^2 buffer of round 2 would no longer have fitted next to the factor
+  timeout 600 python tools/grad_probe.py 131072 > $OUT/grad_probe_131072.txt 2>&1
 fi
 if has fill; then
   stamp "steady fill"
