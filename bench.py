@@ -560,6 +560,9 @@ def run_sharded(args, rank, world, local_rank, n):
     from battgp_amd.sharded import make_sharded_gp
 
     kid, hyp, desc = kernel_setup(args.kernel)
+    fault = os.environ.get("BGP_BENCH_SHARDED_FAULT", "")  # test hook (tests/test_bench_host.py): "raise:<rank>"
+    if fault == f"raise:{rank}":
+        raise RuntimeError("injected fault in the sharded sub-run")
     gp = make_sharded_gp(kid, hyp, nb=args.sharded_nb, backend_name=args.backend, local_rank=local_rank)
     x, y = synthetic.make_cell_data(n)
     xq = synthetic.make_query(x, args.m)
@@ -637,7 +640,7 @@ def main() -> None:
     ap.add_argument("--sharded-nb", type=int, default=1024)
     ap.add_argument("--sharded-steps", type=int, default=1)
     ap.add_argument("--sharded-grad", action="store_true", help="also time ONE analytic LML gradient of the sharded GP (2/3 N^3 flop)")
-    ap.add_argument("--sharded-limit-s", type=float, default=900.0, help="time limit of the sharded sub-run of a multi-GPU cells run")
+    ap.add_argument("--sharded-limit-s", type=float, default=300.0, help="time limit of the sharded sub-run of a multi-GPU cells run")
     ap.add_argument("--force-group", action="store_true",
                     help="build the process group even for ONE process, so that --mode sharded on a 1-GPU box sends every "
                          "broadcast / all-reduce of the schedule through RCCL (single-rank proxy with the collectives in)")

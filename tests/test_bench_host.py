@@ -128,6 +128,41 @@ def test_the_drivers_multi_gpu_launch_of_bench_py_rehearsed_on_the_cpu_build():
     assert sh["lml"] == pytest.approx(OracleGP(KERNEL_MATERN32, synthetic.HYP_MATERN32, xs, ys).fit().lml, rel=1e-9)
 
 
+def test_guarded_sub_run_reports_instead_of_propagating(monkeypatch):
+    """bench._guarded: result, exception and time-out of the sharded sub-run all come back as a value"""
+    import time
+
+    import torch
+
+    import bench
+
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    assert bench._guarded(lambda: {"ok": 1}, 5.0, 0) == ({"ok": 1}, False)
+    rec, hung = bench._guarded(lambda: 1 / 0, 5.0, 0)
+    assert "ZeroDivisionError" in rec["error"] and not hung
+    rec, hung = bench._guarded(lambda: time.sleep(30), 0.2, 0)
+    assert hung and "no result within" in rec["error"]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_a_failing_sharded_sub_run_cannot_take_the_cells_record_down():
+    """the multi-GPU launch with rank 1 raising inside the sharded sub-run (rank 0 then waits in a collective
+    that never completes): the cells record - already measured - is still printed as the ONE JSON line, with the failure
+    as a field, and both ranks leave without the tear-down collectives"""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py",
+           "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "300", "--backend", "gloo", "--share-gpu",
+           "--sharded-n", "256", "--sharded-nb", "128", "--sharded-limit-s", "15"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, BGP_BENCH_SHARDED_FAULT="raise:1"), capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert "error" in out["sharded"], out["sharded"]
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
 def test_side_measurements_cannot_take_the_bench_record_down(tmp_path):
     """the default single-GPU invocation rehearsed on the CPU build, where several side measurements MUST fail (no
@@ -174,7 +209,7 @@ def test_smoke_entry_point_rehearsed_on_the_cpu_build():
     (["tools/ab_lookahead.py", "1", "700"], '"identical_to_default": true'),
     (["tools/large_n.py", "1500"], '"fit_predict_s"'),
     (["bench.py", "--mode", "sharded", "--size", "700", "--kernel", "battgp", "--steps", "1", "--warmup", "1", "--cpu-n", "0",
-      "--no-extras", "--backend", "gloo", "--force-group", "--sharded-nb", "128"], '"scaling": "strong"'),
+      "--no-extras", "--backend", "gloo", "--force-group", "--sharded-nb", "128", "--sharded-grad"], '"lml_grad"'),
 ])
 def test_gpu_session_scripts_rehearsed_on_the_cpu_build(argv, expect):
     """every script tools/gpu_session.sh spends GPU minutes on runs to completion on the CPU build of the kernel sources
