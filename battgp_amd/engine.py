@@ -185,7 +185,9 @@ class ExactGPEngine:
         return self._after_fit(lml, jit)
 
     def lml_grad(self) -> np.ndarray:
-        """d lml / d hyp (same layout as ``hyp``) at the last fit, computed on the GPU."""
+        """d lml / d hyp (same layout as ``hyp``) at the last fit, computed on the GPU.  ``Sigma^-1`` is formed in place
+        over the factor (no second N^2 buffer); a later ``predict`` / ``residuals`` / ``lml_grad`` at the same point
+        transparently re-runs the fit on the resident data (``include/battgp.h``)."""
         g = np.zeros(self.hyp.size, dtype=np.float64)
         self._check(self._lib.bgp_lml_grad(self._h, dptr(g), g.size), "bgp_lml_grad")
         return g

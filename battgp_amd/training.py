@@ -4,8 +4,9 @@ as ``src/gp/training.py`` (``train_exact_gp_adam`` :11-67, ``train_exact_gp_lbfg
 
 Each iteration evaluates ``loss = -mll = -lml / N`` with ONE resident re-fit on the GPU
 (``bgp_refit``: fill + jittered Cholesky, no re-upload) and its gradient with ``bgp_lml_grad``
-(``1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta)``: Sigma^-1 formed by two more N^3/3 MFMA passes
-plus one fused reduction pass); the chain rule to the raw (unconstrained) parameters - what
+(``1/2 tr((alpha alpha^T - Sigma^-1) dSigma/dtheta)``: Sigma^-1 formed IN PLACE over the factor by two more N^3/3
+MFMA passes plus one fused reduction pass - no second N^2 buffer, so training reaches the same N as inference; for an
+``n_devices > 1`` model the same steps run over the ranks' panels, ``ShardedExactGP.lml_grad``); the chain rule to the raw (unconstrained) parameters - what
 ``loss.backward()`` gives the reference - is applied on the host (``BatteryCellGP.neg_mll_and_raw_grad``).
 """
 
