@@ -26,6 +26,53 @@ from .battcellgp_full import BatteryCellGP_Full, build_cellmodel_full
 from .operating_point import Op, get_causal_tag, get_cell_tag
 
 
+class RefStrategy:
+    """Which operating point the system is evaluated at: ``RefStrategy("mean")``, ``RefStrategy("median")`` (of the
+    battery's data) or ``RefStrategy(Op(...))`` - the argument ``gp_runner.py:53-76`` hands to ``BattGP_Full``
+    (``src/batt_models/ref_strategy.py:7-47``: same constructor, same queries, ``ValueError`` for anything else)."""
+
+    def __init__(self, strategy="mean"):
+        self._value = None
+        if isinstance(strategy, str):
+            if strategy not in ("mean", "median"):
+                raise ValueError("Invalid value for 'strategy'")
+            self._kind = strategy
+        elif all(hasattr(strategy, name) for name in ("I", "SOC", "T")):  # an Op (this package's or the reference's)
+            self._kind = "manual"
+            self._value = strategy
+        else:
+            raise ValueError("Invalid value for 'strategy'")
+
+    def is_mean(self) -> bool:
+        return self._kind == "mean"
+
+    def is_median(self) -> bool:
+        return self._kind == "median"
+
+    def is_manual(self) -> bool:
+        return self._kind == "manual"
+
+    def get_manual_value(self):
+        if self._kind != "manual":
+            raise ValueError("manual value can only be given if strategy is 'manual'")
+        return self._value
+
+
+def _resolve_ref_op(batt_data, ref_strategy, ref_op):
+    """The operating point a ``BattGP`` starts with (``src/batt_models/battgp.py:115-121``).  ``ref_strategy`` may be
+    the reference's own ``RefStrategy`` object (anything with ``is_median`` / ``is_mean`` / ``get_manual_value``), this
+    module's, a bare ``"mean"`` / ``"median"`` or an ``Op``; ``ref_op=`` (an addition of this package) wins."""
+    if ref_op is not None:
+        return ref_op
+    if not all(hasattr(ref_strategy, name) for name in ("is_median", "is_mean", "get_manual_value")):
+        ref_strategy = RefStrategy(ref_strategy)
+    if ref_strategy.is_median():
+        return batt_data.median_op
+    if ref_strategy.is_mean():
+        return batt_data.mean_op
+    return ref_strategy.get_manual_value()
+
+
 @dataclass
 class BattGPResult:
     """``src/batt_models/battgp.py:16-92``."""
@@ -74,7 +121,7 @@ class BattGP_Full:
         max_training_data: Optional[int] = None,
         max_age: Optional[int] = None,
         ref_op: Optional[Op] = None,
-        ref_strategy: str = "mean",
+        ref_strategy="mean",
         device=None,
         devices: Optional[list] = None,
         save_path: Optional[str] = None,
@@ -87,12 +134,9 @@ class BattGP_Full:
         self.batt_data = batt_data
         self.max_training_data = max_training_data
         self.max_age = batt_data.age if max_age is None else max_age
-        if ref_op is not None:
-            self.ref_op = ref_op
-        elif ref_strategy == "median":
-            self.ref_op = batt_data.median_op
-        else:
-            self.ref_op = batt_data.mean_op
+        self.ref_strategy = ref_strategy
+        self.ref_op = _resolve_ref_op(batt_data, ref_strategy, ref_op)
+        print(f"Reference operating point: {self.ref_op}")  # battgp.py:122
         self.save_path = None
         if save_path is not None:
             self.save_path = os.path.join(save_path, batt_data.id)
@@ -113,6 +157,16 @@ class BattGP_Full:
         self.t = None
 
     # -- small accessors of the base class (battgp.py:131-179) -------------------------------------
+    def set_operating_point_to_mean(self) -> None:
+        op = self.batt_data.mean_op
+        print(f"Battery operating point set to mean: {op.disp_str()}")
+        self.set_operating_point(op, verbose=False)
+
+    def set_operating_point_to_median(self) -> None:
+        op = self.batt_data.median_op
+        print(f"Battery operating point set to median: {op.disp_str()}")
+        self.set_operating_point(op, verbose=False)
+
     def set_operating_point(self, op: Op, verbose: bool = True) -> None:
         if verbose:
             print(f"Battery operating point set to: {op.disp_str()}")

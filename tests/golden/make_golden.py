@@ -361,7 +361,64 @@ def make_n2048(path: str) -> None:
     print("oracle_n2048.json ok")
 
 
+def make_system_contract(path: str) -> None:
+    """What the reference's importable pure-pandas objects around the hot path answer on fixed inputs
+    (``src/batt_models/battgp.py:16-128``: ``BattGPResult.get_cell_data``, the operating point a ``BattGP`` picks per
+    ``RefStrategy``; ``src/operating_point.py``; ``src/batt_models/cellnr.py``) - stored as data for
+    ``tests/test_reference_consumers.py::test_system_contract_golden``."""
+    sys.path.insert(0, "/root/reference")
+    sys.path.insert(0, os.path.dirname(HERE))
+    import contextlib
+    import io
+
+    import pandas as pd  # noqa: F401
+    from src.batt_models import battgp as ref_battgp
+    from src.batt_models import cellnr as ref_cellnr
+    from src.batt_models.ref_strategy import RefStrategy as RefRefStrategy
+    from src.operating_point import Op as RefOp
+    from test_reference_consumers import CELL_DATA_CALLS, _Data, contract_frame  # the inputs (this repository's)
+
+    frame_args = dict(n_rows=7, cells=[1, 2, 3, 4], seed=3)
+    df = contract_frame(**frame_args)
+    result = ref_battgp.BattGPResult(None, [], RefOp(-15.0, 90.0, 25.0), df)
+    cell_data = []
+    for cellnrs, signals, causal, missing in CELL_DATA_CALLS:
+        try:
+            out = result.get_cell_data(cellnrs, signals, causal, missing)
+        except ValueError:
+            cell_data.append("ValueError")
+            continue
+        # which source column each output column carries: identified by VALUE (every column of the frame is distinct)
+        sources = []
+        for pos in range(out.shape[1]):
+            hits = [c for c in df.columns if np.array_equal(df[c].to_numpy(), out.iloc[:, pos].to_numpy())]
+            assert len(hits) == 1
+            sources.append(hits[0])
+        cell_data.append({"columns": list(out.columns), "sources": sources})
+    ops = [(-15.0, 90.0, 25.0), (-27.123456, 73.5, 18.004), (0, 100, -5)]
+    bd = _Data("g", n_cells=1)
+    picks = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for strategy in ("mean", "median"):
+            picks[strategy] = ref_battgp.BattGP(bd, ref_strategy=RefRefStrategy(strategy)).ref_op.disp_str()
+        manual = ref_battgp.BattGP(bd, ref_strategy=RefRefStrategy(RefOp(1.0, 2.0, 3.0))).ref_op.disp_str()
+    gold = {
+        "frame": frame_args,
+        "frame_columns": list(df.columns),
+        "cell_data": cell_data,
+        "op": [[list(v), RefOp(*v).disp_str(), repr(RefOp(*v))] for v in ops],
+        "cell_tags": [[c, ref_cellnr.get_cell_tag(c)] for c in (-1, 0, 1, 7, 12, 108)],
+        "causal_tags": [ref_cellnr.get_causal_tag(True), ref_cellnr.get_causal_tag(False)],
+        "strategy_picks": picks,
+        "manual_pick": manual,
+    }
+    with open(path, "w") as f:
+        json.dump(gold, f, indent=1)
+    print("system_contract.json ok")
+
+
 if __name__ == "__main__":
+    make_system_contract(os.path.join(HERE, "system_contract.json"))
     make_stgp_egp(os.path.join(HERE, "stgp_egp.npz"))
     make_stgp_long(os.path.join(HERE, "stgp_egp_long.npz"))
     make_lml_pins(os.path.join(HERE, "lml_pins.npz"))
