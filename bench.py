@@ -39,6 +39,60 @@ PEAK_HBM_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 PROFILE_TAG = "r02"  # profiles/<tag>_n<N>_<kernel>_summary.json: committed rocprofv3 PMC passes of this round
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The record is durable: once the timed region is over, whatever ends the process (the caller's time limit = SIGTERM,
+# Ctrl-C) prints the ONE JSON line with what has been measured so far; side measurements run in their own sessions
+# so that a time limit (theirs or ours) ends the whole child tree - a profiler's grandchild would otherwise keep
+# its N^2 factor in HBM underneath the next pass.
+# ---------------------------------------------------------------------------------------------------------------
+_STATE = {"out": None, "printed": False, "children": []}
+
+
+def emit(out) -> None:
+    if out is not None and not _STATE["printed"]:
+        _STATE["printed"] = True
+        print(json.dumps(out), flush=True)
+
+
+def run_child(cmd, timeout, **kw):
+    """subprocess.run(capture_output=True, text=True) in a session of its own; on a timeout the whole session is killed
+    (by the process-group id created here) before subprocess.TimeoutExpired is re-raised."""
+    import signal
+    import subprocess
+
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, **kw)
+    _STATE["children"].append(p)
+    try:
+        so, se = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        p.communicate()
+        raise
+    finally:
+        _STATE["children"].remove(p)
+    return subprocess.CompletedProcess(cmd, p.returncode, so, se)
+
+
+def _on_term(signum, _frame):
+    import signal
+
+    for p in list(_STATE["children"]):
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+    out = _STATE["out"]
+    if out is not None and not _STATE["printed"]:
+        out["interrupted"] = f"signal {signum} during the side measurements: the record holds what was finished by then"
+        out.setdefault("cpu_baseline", None)
+        emit(out)
+    sys.stdout.flush()
+    os._exit(0 if out is not None else 128 + signum)
+
+
 def algorithmic_flop(n: int, m: int) -> float:
     """N^3/3 (Cholesky) + N^2 M (predictive TRSM) + 2 N^2 (two TRSV)."""
     return n**3 / 3.0 + float(n) * n * m + 2.0 * n * n
@@ -185,7 +239,7 @@ def pmc_live(n: int, kernel: str, m: int = 300, limit_s: float = 240.0) -> dict:
                    sys.executable, os.path.join(ROOT, "tools", "profile_workload.py"), str(n), kernel]
             t0 = time.perf_counter()
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=limit_s)
+                r = run_child(cmd, limit_s, cwd="/tmp", env=env)
                 passes[tag] = {"rc": r.returncode, "s": time.perf_counter() - t0}
                 if r.returncode:
                     passes[tag]["stderr_tail"] = r.stderr[-300:]
@@ -461,6 +515,7 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
             "n_max_per_gpu": n_max_from_profile(),
         }
     wl.eng.close()  # frees (or parks) the factor before the scratch-sized side measurements
+    _STATE["out"] = out  # from here on a SIGTERM prints the record (rank 0) instead of losing it
     if rank == 0 and world == 1 and not args.no_extras:
         from battgp_amd.engine import trim_pool
 
@@ -517,6 +572,8 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
                   for en, ek in ((args.extra_n, "battgp"),) if en > 0 and not (en == n and ek == args.kernel)]
         out["extra_configs"] = [e for e in extras if e]
         trim_pool(local_rank)  # the children below need the HBM
+        # required field before optional evidence: the host-side baseline comes ahead of the profiler passes and the A/B
+        host_baseline(out, args)
         if not args.no_pmc:
             # three passes of one fit+predict each (+ process start): the step time is the best estimate of a pass
             pass_s = 3.0 * (elapsed / args.steps) + 30.0
@@ -535,6 +592,18 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
     return out
 
 
+def host_baseline(out, args) -> None:
+    """out["cpu_baseline"]: the oracle's dense path on this box's host cores (bounded samples); never raises."""
+    if "cpu_baseline" in out:
+        return
+    if args.cpu_n <= 0:
+        return
+    try:
+        out["cpu_baseline"] = cpu_baseline(args.kernel, args.cpu_n, args.m, args.cpu_n2, args.cpu_budget_s)
+    except Exception as exc:  # noqa: BLE001 - the GPU record is printed whatever happens to the host-side sample
+        out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"[:300]}
+
+
 def schedule_experiments(limit_s: float = 150.0):
     """A/B of the optional Cholesky schedules (tools/ab_lookahead.py) in a CHILD process with a time limit: they are
     off by default until measured, and nothing they do can reach the record above."""
@@ -542,7 +611,7 @@ def schedule_experiments(limit_s: float = 150.0):
 
     cmd = [sys.executable, os.path.join(ROOT, "tools", "ab_lookahead.py"), "3", "4096", "16384", "40000"]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+        r = run_child(cmd, limit_s)
         lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
         return {"what": "fit+predict ms by lookahead word (1 default, +32 slim chain kernels, +64 split panels, +128 fused update + tile Cholesky), panel scheme 1",
                 "rc": r.returncode, "runs": lines, "stderr_tail": r.stderr[-300:] if r.returncode else ""}
@@ -645,6 +714,10 @@ def main() -> None:
                     help="build the process group even for ONE process, so that --mode sharded on a 1-GPU box sends every "
                          "broadcast / all-reduce of the schedule through RCCL (single-rank proxy with the collectives in)")
     args = ap.parse_args()
+    import signal
+
+    signal.signal(signal.SIGTERM, _on_term)
+    signal.signal(signal.SIGINT, _on_term)
     if args.force_group:
         os.environ["BGP_FORCE_GROUP"] = "1"
 
@@ -687,14 +760,11 @@ def main() -> None:
         if rank == 0:
             if sh is not None:
                 out["sharded"] = sh
-            if args.cpu_n > 0 and world == 1:
-                try:
-                    out["cpu_baseline"] = cpu_baseline(args.kernel, args.cpu_n, args.m, args.cpu_n2, args.cpu_budget_s)
-                except Exception as exc:  # noqa: BLE001 - the GPU record is printed whatever happens to the host-side sample
-                    out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"[:300]}
-            elif world > 1:
+            if world == 1:
+                host_baseline(out, args)
+            else:
                 out["cpu_baseline"] = None
-            print(json.dumps(out), flush=True)
+            emit(out)
     if dist is not None:
         if hung or (isinstance(sh, dict) and "error" in sh):
             # a rank of the group is stuck or gone: the tear-down collectives would wait for it - the line is out, leave

@@ -238,3 +238,49 @@ def test_side_measurements_respect_their_time_budget():
     assert set(errs) == {"fill_steady", "extra_300_battgp", "pmc_live", "experiments"} and all(v.startswith("skipped") for v in errs.values())
     assert out["extra_configs"] == [] and out["pmc_live"] is None and out["experiments"] is None
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_a_time_limit_during_the_side_measurements_still_prints_the_record(tmp_path):
+    """the caller's time limit (SIGTERM) arriving while a profiler pass is running: the ONE JSON line comes out with the
+    timed region, the roofline objects and the host baseline that were finished by then, flagged `interrupted`, and the
+    profiler's process tree (its own session) is gone"""
+    import signal
+    import subprocess
+    import time
+
+    marker = tmp_path / "started"
+    slow = tmp_path / "rocprofv3"
+    slow.write_text(f"#!/bin/sh\necho $$ > {marker}\nsleep 300 &\necho $! >> {marker}\nwait\n")
+    slow.chmod(0o755)
+    env = dict(os.environ, BGP_ROCPROFV3=str(slow))
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py", "--steps", "1", "--warmup", "0", "--size", "600",
+           "--extra-n", "0", "--cpu-n", "300", "--cpu-n2", "0"]
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        t0 = time.time()
+        while time.time() - t0 < 500 and not (marker.exists() and len(marker.read_text().split()) == 2):
+            assert p.poll() is None, p.communicate()
+            time.sleep(0.2)
+        pids = [int(v) for v in marker.read_text().split()]
+        p.send_signal(signal.SIGTERM)
+        so, se = p.communicate(timeout=60)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert p.returncode == 0, so[-1500:] + se[-1500:]
+    lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert "signal 15" in out["interrupted"] and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["roofline_fill"]["achieved"] > 0
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0  # gathered BEFORE the profiler passes
+    time.sleep(0.5)
+    for pid in pids:  # the stand-in profiler and its child were killed with their session
+        alive = True
+        try:
+            os.kill(pid, 0)
+            with open(f"/proc/{pid}/stat") as f:
+                alive = f.read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
