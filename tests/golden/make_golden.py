@@ -361,6 +361,89 @@ def make_n2048(path: str) -> None:
     print("oracle_n2048.json ok")
 
 
+def make_sklearn_pins(path: str) -> None:
+    """An independent third-party exact GP on the kernels the reference cannot pin (it has no Matern at all, and its
+    RBF models only through gpytorch, which is absent here): scikit-learn's ``GaussianProcessRegressor`` (Rasmussen &
+    Williams alg. 2.1 on LAPACK, no jitter, ``optimizer=None``) with ``ConstantKernel * Matern(nu=1.5) / RBF``:
+
+    * ``log_marginal_likelihood(theta, eval_gradient=True)`` with a ``WhiteKernel`` noise term: the LML and its gradient
+      with respect to ``log`` of every hyper-parameter (stored converted to ``d lml / d theta`` in the C-ABI's layout
+      ``[noise, s, l_1 ..]``);
+    * ``predict(return_std=True)`` with the noise as ``alpha`` (training diagonal only), i.e. the posterior of the LATENT
+      function like ``battcellgp_full.py:171-180``.
+
+    Nothing of this repository's oracle or engine takes part in the stored numbers; the oracle is checked against them
+    before anything is written."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, WhiteKernel
+
+    from oracle.exact_gp import lml_and_grad
+
+    out = {}
+    worst = {"lml": 0.0, "mean": 0.0, "var": 0.0, "grad": 0.0}
+    cases = [
+        ("k2", K.KERNEL_MATERN32, synthetic.HYP_MATERN32, False),
+        ("k2b", K.KERNEL_MATERN32, np.array([1e-4, 0.5, 300.0, 20.0, 15.0, 12.0]), False),
+        ("k3", K.KERNEL_ARD_RBF, np.array([2.33e-6, 0.0099, 500.0, 12.11, 33.75, 45.14]), False),
+        ("k1", K.KERNEL_SCALED_RBF, np.array([2.33e-6, 0.0099, 3.0]), True),
+    ]
+    for name, kid, hyp, standardised in cases:
+        for n in (10, 64, 400):
+            x, y = synthetic.make_cell_data(n, seed=500 + n)
+            xq = synthetic.make_query(x, 24)
+            if standardised:
+                mu, sd = x.mean(axis=0), x.std(axis=0)
+                x, xq = (x - mu) / sd, (xq - mu) / sd
+            noise_var, s = hyp[0], hyp[1]
+            ls = np.full(x.shape[1], hyp[2]) if kid == K.KERNEL_SCALED_RBF else hyp[2:]
+            if kid == K.KERNEL_MATERN32:
+                base = Matern(length_scale=ls, nu=1.5)
+            elif kid == K.KERNEL_SCALED_RBF:
+                base = RBF(length_scale=float(hyp[2]))
+            else:
+                base = RBF(length_scale=ls)
+            # (1) LML + gradient: noise inside the kernel
+            kern = ConstantKernel(s) * base + WhiteKernel(noise_var)
+            gpr = GaussianProcessRegressor(kernel=kern, alpha=0.0, optimizer=None, normalize_y=False).fit(x, y)
+            lml, g_log = gpr.log_marginal_likelihood(gpr.kernel_.theta, eval_gradient=True)
+            # theta = log of [constant_value, length_scale(s), noise_level]
+            n_ls = 1 if kid == K.KERNEL_SCALED_RBF else x.shape[1]
+            grad = np.empty(hyp.size)
+            grad[0] = g_log[-1] / noise_var
+            grad[1] = g_log[0] / s
+            grad[2:] = g_log[1 : 1 + n_ls] / hyp[2:]
+            # (2) latent posterior: noise on the training diagonal only
+            gpl = GaussianProcessRegressor(kernel=ConstantKernel(s) * base, alpha=noise_var, optimizer=None, normalize_y=False).fit(x, y)
+            mean, std = gpl.predict(xq, return_std=True)
+            var = std * std
+            # the oracle agrees before anything is written
+            gp = OracleGP(kid, hyp, x, y).fit()
+            o_mean, o_var = gp.predict(xq, clamp=False)
+            _, o_grad = lml_and_grad(kid, hyp, x, y)
+            assert gp.jitter == 0.0
+            e = {
+                "lml": abs(gp.lml - lml) / abs(lml),
+                "mean": np.abs(o_mean - mean).max() / np.abs(mean).max(),
+                "var": np.abs(o_var - var).max() / s,
+                "grad": np.max(np.abs(o_grad - grad) / (np.abs(grad) + 1e-6 * np.abs(grad).max())),
+            }
+            assert e["lml"] < 1e-9 and e["mean"] < 1e-7 and e["var"] < 1e-7 and e["grad"] < 1e-5, (name, n, e)
+            for k_, v in e.items():
+                worst[k_] = max(worst[k_], float(v))
+            pre = f"{name}_n{n}_"
+            out[pre + "kernel_id"] = np.int64(kid)
+            out[pre + "hyp"] = hyp
+            out[pre + "x"] = x
+            out[pre + "y"] = y
+            out[pre + "xq"] = xq
+            out[pre + "lml"] = np.float64(lml)
+            out[pre + "grad"] = grad
+            out[pre + "mean"] = mean
+            out[pre + "var"] = var
+    np.savez_compressed(path, **out)
+    print("sklearn_pins.npz ok; oracle vs scikit-learn, worst:", {k_: f"{v:.1e}" for k_, v in worst.items()})
+
+
 def make_system_contract(path: str) -> None:
     """What the reference's importable pure-pandas objects around the hot path answer on fixed inputs
     (``src/batt_models/battgp.py:16-128``: ``BattGPResult.get_cell_data``, the operating point a ``BattGP`` picks per
@@ -419,6 +502,7 @@ def make_system_contract(path: str) -> None:
 
 if __name__ == "__main__":
     make_system_contract(os.path.join(HERE, "system_contract.json"))
+    make_sklearn_pins(os.path.join(HERE, "sklearn_pins.npz"))
     make_stgp_egp(os.path.join(HERE, "stgp_egp.npz"))
     make_stgp_long(os.path.join(HERE, "stgp_egp_long.npz"))
     make_lml_pins(os.path.join(HERE, "lml_pins.npz"))

@@ -90,6 +90,34 @@ def test_stgp_egp_long_golden_on_gpu(golden_dir, name):
         e.close()
 
 
+@pytest.mark.parametrize("name", ["k2", "k2b", "k3", "k1"])
+@pytest.mark.parametrize("n", [10, 64, 400])
+def test_matern_and_rbf_match_scikit_learn_pins(golden_dir, name, n):
+    """Matern-3/2 (BASELINE config 3's kernel, which the reference cannot pin - it has none) and the RBF kernels against
+    an independent third-party exact GP, scikit-learn's GaussianProcessRegressor (make_golden.py::make_sklearn_pins):
+    LML, the analytic LML gradient (in-place Sigma^-1 + reduction pass), latent posterior mean and variance, through
+    fit + predict and through the fused call."""
+    g = np.load(os.path.join(golden_dir, "sklearn_pins.npz"))
+    p = f"{name}_n{n}_"
+    kid, hyp, x, y, xq = int(g[p + "kernel_id"]), g[p + "hyp"], g[p + "x"], g[p + "y"], g[p + "xq"]
+    want, wgrad = float(g[p + "lml"]), g[p + "grad"]
+    e = ExactGPEngine(kid, hyp)
+    try:
+        lml = e.fit(x, y)
+        assert e.jitter == 0.0
+        m, v = e.predict(xq, min_var=-1.0)
+        grad = e.lml_grad()
+        m_after, v_after = e.predict(xq, min_var=-1.0)  # the factor the gradient consumed is restored on demand
+        lml2, m2, v2 = e.fit_predict(x, y, xq, min_var=-1.0)
+    finally:
+        e.close()
+    assert np.all(np.abs(grad - wgrad) <= 1e-5 * np.abs(wgrad) + 1e-7 * np.abs(wgrad).max()), (grad, wgrad)
+    for ll, mm, vv in ((lml, m, v), (lml, m_after, v_after), (lml2, m2, v2)):
+        assert abs(ll - want) <= REL * abs(want), (ll, want)
+        assert np.linalg.norm(mm - g[p + "mean"]) <= REL * np.linalg.norm(mm)
+        assert np.max(np.abs(vv - g[p + "var"])) <= REL * np.max(np.abs(vv)) + 1e-9 * hyp[1]
+
+
 # ---------------------------------------------------------------------------------------------
 # (b) natural sizes
 # ---------------------------------------------------------------------------------------------

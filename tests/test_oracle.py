@@ -195,3 +195,38 @@ def test_lml_gradient_finite_difference(kid):
         hm[i] -= h
         fd = (OracleGP(kid, hp, x, y).fit().lml - OracleGP(kid, hm, x, y).fit().lml) / (2 * h)
         assert abs(fd - grad[i]) < 1e-5 * max(1.0, abs(grad[i])), (i, fd, grad[i])
+
+
+SKLEARN_CASES = [(name, n) for name in ("k2", "k2b", "k3", "k1") for n in (10, 64, 400)]
+
+
+@pytest.mark.parametrize("name,n", SKLEARN_CASES)
+def test_matern_and_rbf_pinned_by_scikit_learn(golden_dir, name, n):
+    """The kernels no reference test or call site pins (Matern-3/2: the reference has none; RBF: only through the absent
+    gpytorch) against an independent third-party exact GP - scikit-learn's GaussianProcessRegressor
+    (tests/golden/make_golden.py::make_sklearn_pins): LML, its gradient w.r.t. every hyper-parameter, latent posterior
+    mean and variance; north-star tolerance 1e-6 (measured 3e-13 / 4e-11 / 4e-12 / 5e-15)."""
+    g = np.load(os.path.join(golden_dir, "sklearn_pins.npz"))
+    p = f"{name}_n{n}_"
+    kid, hyp, x, y, xq = int(g[p + "kernel_id"]), g[p + "hyp"], g[p + "x"], g[p + "y"], g[p + "xq"]
+    lml, grad = lml_and_grad(kid, hyp, x, y)
+    assert abs(lml - g[p + "lml"]) <= 1e-9 * abs(g[p + "lml"])
+    assert np.all(np.abs(grad - g[p + "grad"]) <= 1e-6 * np.abs(g[p + "grad"]) + 1e-9 * np.abs(g[p + "grad"]).max())
+    m, v = OracleGP(kid, hyp, x, y).fit().predict(xq, clamp=False)
+    assert np.linalg.norm(m - g[p + "mean"]) <= 1e-8 * np.linalg.norm(m)
+    assert np.max(np.abs(v - g[p + "var"])) <= 1e-8 * hyp[1]
+
+
+def test_scikit_learn_pins_regenerate(golden_dir, tmp_path):
+    """scikit-learn is in the image: the committed pins are what it computes today (live re-run of the generator)"""
+    pytest.importorskip("sklearn")
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_mk_golden", os.path.join(golden_dir, "make_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    mk.make_sklearn_pins(str(tmp_path / "again.npz"))
+    a, b = np.load(tmp_path / "again.npz"), np.load(os.path.join(golden_dir, "sklearn_pins.npz"))
+    assert sorted(a.files) == sorted(b.files)
+    for key in a.files:
+        assert np.allclose(a[key], b[key], rtol=1e-12, atol=0.0), key
