@@ -286,6 +286,57 @@ def make_lml_pins(path: str) -> None:
     print("lml_pins.npz ok")
 
 
+def make_grad_pins(path: str) -> None:
+    """``d lml / d theta`` of the production kernel by torch AUTOGRAD through ``MultivariateNormal.log_prob`` of the
+    torch-assembled covariance - the computation behind ``loss.backward()`` at ``src/gp/training.py:39-41`` (there through
+    gpytorch's modules, here through the restated assembly above with the hyper-parameters as differentiable tensors).
+    Independent of the oracle's and the engine's closed-form trace formula ``1/2 tr((alpha alpha^T - Sigma^-1) dSigma)``."""
+    import torch
+
+    out = {}
+    for n in (10, 64, 256):
+        x, y = synthetic.make_cell_data(n, seed=9000 + n)
+        xs = synthetic.standardise(x)
+        cases = {
+            "k0prod": (K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y),
+            "k0test": (K.KERNEL_BATTGP, np.array([0.1, 10.0, 3.0, 2.0, 2.0, 2.0]), np.column_stack((x[:, 0] / 120.0, xs[:, 1:])), (y - y.mean()) * 1e3),
+            "k1": (K.KERNEL_SCALED_RBF, np.array([3.0, 3.0, 2.0]), xs, (y - y.mean()) * 1e3),
+        }
+        for name, (kid, hyp, xx, yy) in cases.items():
+            th = torch.tensor(hyp, dtype=torch.float64, requires_grad=True)
+            xt = torch.as_tensor(xx, dtype=torch.float64)
+            if kid == K.KERNEL_BATTGP:
+                t = xt[:, :1]
+                distance = _gpytorch_sq_dist(t, t, True).clamp_min(1e-30).sqrt()
+                minval = torch.minimum(t, t.T)  # (the column loop of wiener_kernel.py:21-22, vectorised)
+                wiener = minval.pow(3) / 3 + distance * minval.pow(2) / 2
+                z = xt[:, 1:] / th[3:].reshape(1, -1)
+                kmat = th[1] * wiener + th[2] * _gpytorch_sq_dist(z, z, True).div(-2).exp()
+            else:
+                z = xt / th[2]
+                kmat = th[1] * _gpytorch_sq_dist(z, z, True).div(-2).exp()
+            sigma = kmat + th[0] * torch.eye(n, dtype=torch.float64)
+            mvn = torch.distributions.MultivariateNormal(torch.zeros(n, dtype=torch.float64), covariance_matrix=sigma)
+            lml = mvn.log_prob(torch.as_tensor(yy, dtype=torch.float64))
+            lml.backward()
+            grad = th.grad.numpy().copy()
+            from oracle.exact_gp import lml_and_grad
+
+            o_lml, o_grad = lml_and_grad(kid, hyp, xx, yy)
+            rel = np.max(np.abs(o_grad - grad) / (np.abs(grad) + 1e-6 * np.abs(grad).max()))
+            assert abs(o_lml - lml.item()) < 1e-9 * abs(lml.item()) and rel < 1e-5, (name, n, rel, o_grad, grad)
+            print(f"  grad pin {name} n={n}: oracle vs autograd, worst component rel {rel:.1e}")
+            p = f"{name}_n{n}_"
+            out[p + "kernel_id"] = np.int64(kid)
+            out[p + "hyp"] = np.asarray(hyp, dtype=np.float64)
+            out[p + "x"] = xx
+            out[p + "y"] = yy
+            out[p + "lml"] = np.float64(lml.item())
+            out[p + "grad"] = grad
+    np.savez_compressed(path, **out)
+    print("grad_pins.npz ok")
+
+
 def _case(kernel_id, hyp, x, y, xq):
     gp = OracleGP(kernel_id, hyp, x, y).fit()
     mean, var = gp.predict(xq, clamp=False)
@@ -503,6 +554,7 @@ def make_system_contract(path: str) -> None:
 if __name__ == "__main__":
     make_system_contract(os.path.join(HERE, "system_contract.json"))
     make_sklearn_pins(os.path.join(HERE, "sklearn_pins.npz"))
+    make_grad_pins(os.path.join(HERE, "grad_pins.npz"))
     make_stgp_egp(os.path.join(HERE, "stgp_egp.npz"))
     make_stgp_long(os.path.join(HERE, "stgp_egp_long.npz"))
     make_lml_pins(os.path.join(HERE, "lml_pins.npz"))

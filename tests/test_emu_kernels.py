@@ -107,6 +107,11 @@ def test_scikit_learn_pins_through_the_kernels(emu, golden_dir, name, n):
     _load("test_gpu_pins_and_sizes").test_matern_and_rbf_match_scikit_learn_pins(golden_dir, name, n)
 
 
+@pytest.mark.parametrize("name,n", [("k0prod", 256), ("k0test", 64), ("k1", 10)])
+def test_autograd_gradient_pins_through_the_kernels(emu, golden_dir, name, n):
+    _load("test_gpu_pins_and_sizes").test_lml_gradient_matches_torch_autograd_pins(golden_dir, name, n)
+
+
 def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
     """Several outer panels at a CPU-sized N (nb_outer = 128, N = 600): panel schemes 0 and 1, look-ahead off / depth 1 /
     depth 2 / ordered, the column-slab layout, the in-place inverse gradient and the explicit-inverse backward solve - the code

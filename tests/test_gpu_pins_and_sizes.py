@@ -118,6 +118,30 @@ def test_matern_and_rbf_match_scikit_learn_pins(golden_dir, name, n):
         assert np.max(np.abs(vv - g[p + "var"])) <= REL * np.max(np.abs(vv)) + 1e-9 * hyp[1]
 
 
+@pytest.mark.parametrize("name", ["k0prod", "k0test", "k1"])
+@pytest.mark.parametrize("n", [10, 64, 256])
+def test_lml_gradient_matches_torch_autograd_pins(golden_dir, name, n):
+    """bgp_lml_grad (Sigma^-1 in place over the factor + the fused reduction pass) against torch AUTOGRAD through
+    MultivariateNormal.log_prob of the torch-assembled covariance - the computation behind loss.backward() at
+    src/gp/training.py:39-41 - for the production kernel with the production and the reference test's hyper-parameters
+    and for ScaledRBFModel's kernel (make_golden.py::make_grad_pins); full square and column slabs."""
+    g = np.load(os.path.join(golden_dir, "grad_pins.npz"))
+    p = f"{name}_n{n}_"
+    kid, hyp, x, y, want = int(g[p + "kernel_id"]), g[p + "hyp"], g[p + "x"], g[p + "y"], g[p + "grad"]
+    for slab in (-1, 64):
+        e = ExactGPEngine(kid, hyp)
+        try:
+            if slab > 0:
+                e.set_options(nb_outer=slab)  # (a slab is a whole number of outer panels)
+            e.set_layout(slab)
+            lml = e.fit(x, y)
+            grad = e.lml_grad()
+        finally:
+            e.close()
+        assert abs(lml - g[p + "lml"]) <= REL * abs(g[p + "lml"])
+        assert np.all(np.abs(grad - want) <= 1e-5 * np.abs(want) + 1e-7 * np.abs(want).max()), (slab, grad, want)
+
+
 # ---------------------------------------------------------------------------------------------
 # (b) natural sizes
 # ---------------------------------------------------------------------------------------------

@@ -230,3 +230,16 @@ def test_scikit_learn_pins_regenerate(golden_dir, tmp_path):
     assert sorted(a.files) == sorted(b.files)
     for key in a.files:
         assert np.allclose(a[key], b[key], rtol=1e-12, atol=0.0), key
+
+
+@pytest.mark.parametrize("name", ["k0prod", "k0test", "k1"])
+@pytest.mark.parametrize("n", [10, 64, 256])
+def test_lml_gradient_pinned_by_torch_autograd(golden_dir, name, n):
+    """d lml / d theta of the production kernel against torch autograd through MultivariateNormal.log_prob of the
+    torch-assembled covariance - what loss.backward() does at src/gp/training.py:39-41 (make_golden.py::make_grad_pins)"""
+    g = np.load(os.path.join(golden_dir, "grad_pins.npz"))
+    p = f"{name}_n{n}_"
+    lml, grad = lml_and_grad(int(g[p + "kernel_id"]), g[p + "hyp"], g[p + "x"], g[p + "y"])
+    want = g[p + "grad"]
+    assert abs(lml - g[p + "lml"]) <= 1e-9 * abs(g[p + "lml"])
+    assert np.all(np.abs(grad - want) <= 1e-6 * np.abs(want) + 1e-9 * np.abs(want).max()), (grad, want)
