@@ -33,3 +33,13 @@ from problem_gen import check_problem, problems  # noqa: E402
 @given(problems())
 def test_random_problems_match_the_oracle_on_the_cpu_build(emu, prob):
     check_problem(*prob)
+
+
+def test_random_sharded_problems_match_the_oracle_on_the_cpu_build():
+    """the same property for the SHARDED driver's device path (one rank, DeviceBackend): tests/emu/sharded_fuzz.py,
+    derandomised, in a process of its own (torch's CUDA entry points are faked there)"""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "sharded_fuzz.py"), "40", "330", "derandomize"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok: 40 sharded problems" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
