@@ -244,3 +244,104 @@ def test_system_contract_golden(golden_dir):
     for strategy, want in gold["strategy_picks"].items():
         assert _resolve_ref_op(bd, strategy, None).disp_str() == want
     assert _resolve_ref_op(bd, RefStrategy(Op(1.0, 2.0, 3.0)), None).disp_str() == gold["manual_pick"]
+
+
+# ---- the reference's own ETL in front of the engine: gp_runner.py's full_gp flow, reference code on both sides -----------
+def _write_raw_field_data(folder, batt_id="syn", rows=2600, seed=21):
+    """A raw field-data file in the layout ``src/batt_data/data_utils.py`` reads (``data_sys_<id>.csv``, the column names of
+    ``data_columns.py``): an 8s1p pack over ~430 days whose cell voltages follow ``U = OCV(SOC) + I R0`` with a known
+    ``R0(t, T)`` per cell, a share of rows outside the segment limits of ``config.py:99-111`` and a few NaNs for the
+    clean-up to remove.  Returns the true resistance function."""
+    rng = np.random.default_rng(seed)
+    ocv = pd.read_csv(os.path.join(REF_ROOT, "data", "ocv_linear_approx.csv"))
+    t_days = np.sort(rng.uniform(0.0, 430.0, rows))
+    index = pd.Timestamp("2021-03-01") + pd.to_timedelta(np.round(t_days * 86400.0), unit="s")
+    soc = rng.uniform(35.0, 99.0, rows)
+    i_batt = rng.uniform(-90.0, 0.0, rows)
+    temps = 25.0 + 12.0 * np.sin(2 * np.pi * t_days / 365.0)[:, None] + rng.normal(0.0, 1.0, (rows, 4))
+    ocv_cell = np.interp(soc, ocv["SOC"], ocv["OCV"])
+
+    def r0_true(cell, t, temp):
+        return 0.012 + 0.002 * np.exp(-(temp - 10.0) / 20.0) + 1.5e-6 * t + 1.5e-4 * ((cell * 7) % 5 - 2)
+
+    cols = {"SOC_Battery": soc, "I_Battery": i_batt}
+    for k in range(4):
+        cols[f"Temperature_{k + 1}"] = temps[:, k]
+    u_sum = np.zeros(rows)
+    for c in range(1, 9):
+        i_cnv = rng.normal(0.0, 1.0, rows)
+        i_cnv[rng.random(rows) < 0.02] = 25.0  # balancing current outside CNV_LIMIT: the row is not a valid segment
+        u = ocv_cell + (i_batt + i_cnv) * r0_true(c, t_days, temps[:, (c - 1) // 2]) + rng.normal(0.0, 2e-4, rows)
+        cols[f"U_Cell_{c}"] = u
+        cols[f"I_CNV_Cell_{c}"] = i_cnv
+        cols[f"T_CNV_Cell_{c}"] = temps[:, (c - 1) // 2] + 5.0  # read, not imported (data_columns.py: None)
+        cols[f"SOC_Cell_{c}"] = soc
+        u_sum += u
+    cols["U_Battery"] = u_sum
+    cols["U_CR"] = np.zeros(rows)
+    cols["I_CR"] = np.zeros(rows)
+    df = pd.DataFrame(cols, index=index)
+    df.index.name = "time_stamp"
+    df.iloc[5, 3] = np.nan
+    df.iloc[77, 0] = np.inf
+    df = df[~df.index.duplicated(keep="first")]
+    df.to_csv(os.path.join(folder, f"data_sys_{batt_id}.csv"))
+    return r0_true
+
+
+def test_gp_runner_full_gp_flow_with_the_reference_etl_in_front(ref, emu, tmp_path, monkeypatch):
+    """``gp_runner.py:44-124`` (``MODE = "full_gp"``, plots aside): raw field data -> the REFERENCE's ``BattData`` (clean-up,
+    float32 cache, segment selection, gap removal, ``R = (U - OCV) / I``, even-index sub-sampling) -> ``BattGP_Full`` of this
+    package with the reference's ``RefStrategy(Op)`` -> ``train`` off (``HYPER_OPT_PARAMS["optimize"]`` is False in
+    ``config.py``) -> ``predict_cell_r0_op`` -> the REFERENCE's ``calc_fault_probabilities``.  The engine (CPU build of the
+    kernel sources here) sits between reference code on both sides, unchanged; every result column equals an oracle GP on
+    what the reference's ``generateTrainingData`` hands over, and the resistance it reports is the one the file was made
+    with."""
+    import src.config as cfg
+    from src.batt_data.batt_data import BattData
+    from src.batt_data.data_utils import read_cell_characteristics
+
+    from battgp_amd.battgp_full import BattGP_Full
+    from oracle import kernels as K
+    from oracle.exact_gp import OracleGP
+
+    raw_dir, cache_dir = tmp_path / "raw", tmp_path / "cache"
+    raw_dir.mkdir()
+    cache_dir.mkdir()
+    r0_true = _write_raw_field_data(str(raw_dir))
+    monkeypatch.setattr(cfg, "PATH_FIELDDATA_DATA", str(raw_dir))
+    monkeypatch.setattr(cfg, "PATH_DATA_CACHE", str(cache_dir))
+    cell_ocv = read_cell_characteristics(os.path.join(REF_ROOT, "data", "ocv_linear_approx.csv"))
+    battdata = BattData("syn", cell_ocv, segment_selection=True, gap_removal=cfg.GAP_REMOVAL, min_data_threshold=1000)
+    assert battdata.cell_nrs == list(range(1, 9)) and 1000 <= len(battdata.df) < 2600  # the segment filter removed rows
+    # the stand-in of this package offers the same contract as the real class
+    stand_in = synthetic.SyntheticBattData("x", n_cells=8)
+    for attr in ("id", "age", "cell_nrs", "mean_op", "median_op", "generateTrainingData"):
+        assert hasattr(stand_in, attr) and hasattr(battdata, attr)
+
+    n_train = 160
+    op = ref.op.Op(-15, 90, 25)  # gp_runner.py:32
+    model = BattGP_Full(battdata, ref_strategy=ref.ref_strategy.RefStrategy(op), max_training_data=n_train, max_age=None,
+                        device=0, save_path=str(tmp_path / "results"))
+    gp_res = model.predict_cell_r0_op()
+    df = gp_res.df
+    assert df.shape == (300, 1 + 2 * 9) and np.isfinite(df.to_numpy()).all()
+    t = df["t"].to_numpy()
+    xq = np.column_stack((t, np.full(300, float(op.I)), np.full(300, float(op.SOC)), np.full(300, float(op.T))))
+    hyp = np.array([cfg.NOISE_VARIANCE[0] if isinstance(cfg.NOISE_VARIANCE, tuple) else cfg.NOISE_VARIANCE, cfg.OUTPUTSCALE_WIENER,
+                    cfg.OUTPUTSCALE_RBF, *cfg.LENGTHSCALE_RBF], dtype=np.float64)
+    for c in (-1, *battdata.cell_nrs):
+        x, y = battdata.generateTrainingData(c, n_train, None)
+        assert x.shape == (n_train, 4) and x[0, 0] == 0.0  # time restarts at the first kept sample (batt_data.py:90-94)
+        mean, var = OracleGP(K.KERNEL_BATTGP, hyp, x, y).fit().predict(xq)
+        tag = get_cell_tag(c)
+        assert np.linalg.norm(df[f"r0_acausal_{tag}"] - mean) <= 1e-6 * np.linalg.norm(mean), tag
+        assert np.max(np.abs(df[f"r0var_acausal_{tag}"] - var)) <= 1e-6 * np.max(var) + 1e-12, tag
+        if c > 0:  # the engine reports the resistance the file was generated with (25 degC, inside the data's time span)
+            inner = (t > 30.0) & (t < t[-1] - 30.0)
+            assert np.max(np.abs(df[f"r0_acausal_{tag}"].to_numpy()[inner] - r0_true(c, t[inner], 25.0))) < 6e-4, tag
+    for band in 10 ** (-3) * np.array([0.55]):  # gp_runner.py:31
+        faults = ref.faults.calc_fault_probabilities(gp_res, causal=False, r0_band=band, r0_upper_threshold=2.0e-3)
+        vals = faults.filter(like="fault prob").to_numpy(dtype=float)
+        assert faults.shape[0] == 300 and np.isfinite(vals).all() and vals.min() >= 0.0 and vals.max() <= 1.0
+    assert os.path.exists(tmp_path / "results" / "syn" / "battgpf_df.feather")
