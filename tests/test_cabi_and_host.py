@@ -4,6 +4,7 @@ fails loudly without a GPU; host-side logic of the reference-shaped adaptor."""
 import math
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -288,3 +289,55 @@ def test_operating_point_record_and_tags():
     assert op.into_array()[2] == 30.0
     assert [get_cell_tag(c) for c in (-1, 0, 12)] == ["pack", "c0", "c12"]
     assert (get_causal_tag(True), get_causal_tag(False)) == ("causal", "acausal")
+
+
+def test_header_is_plain_c_and_a_c_program_drives_the_abi(tmp_path):
+    """include/battgp.h compiles as pedantic C99 (it is the boundary an FFI binds, not a C++ header), and a plain-C
+    caller (tests/cabi/c_caller.c) drives create / set_kernel / fit / predict / refit / lml_grad / destroy through it:
+    linked against the CPU build of the kernel sources it reproduces the known answers of the reference's own unit
+    test and the oracle's LML and gradient of a production-kernel problem; linked against the product library on this
+    GPU-less box it must stop at bgp_create with an error code and a message - never compute anything."""
+    import shutil
+    import subprocess
+
+    from battgp_amd import _lib, synthetic
+    from oracle import kernels as K
+    from oracle.exact_gp import lml_and_grad
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = os.path.join(ROOT, "tests", "cabi", "c_caller.c")
+    flags = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), src]
+    # (a) the product library: links (every symbol the program uses is exported), and without a GPU fails loudly
+    if os.path.exists(_lib.LIB_PATH):
+        exe = str(tmp_path / "c_caller_product")
+        subprocess.run(flags + ["-L" + os.path.dirname(_lib.LIB_PATH), "-lbattgp", "-lm", "-o", exe], check=True, capture_output=True)
+        try:
+            import torch
+
+            have_gpu = torch.cuda.is_available()
+        except Exception:
+            have_gpu = False
+        if not have_gpu:
+            env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(_lib.LIB_PATH) + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+            r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+            assert r.returncode == 77 and "bgp_create failed" in r.stderr and "c_caller ok" not in r.stdout, (r.returncode, r.stderr)
+    # (b) the CPU build of the same sources: the program's checks, plus LML and gradient against the oracle
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("needs the ROCm host clang to build the CPU stand-in")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+
+    emu_so = build_emu.build()
+    exe = str(tmp_path / "c_caller_emu")
+    name = os.path.splitext(os.path.basename(emu_so))[0][3:]
+    subprocess.run(flags + ["-L" + os.path.dirname(emu_so), "-l" + name, "-lm", "-o", exe], check=True, capture_output=True)
+    n, d = 90, 4
+    x, y = synthetic.make_cell_data(n, seed=31)
+    lml, grad = lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)
+    args = [str(n), str(d), repr(float(lml))] + [repr(float(v)) for v in x.ravel()] + [repr(float(v)) for v in y] + [repr(float(v)) for v in synthetic.HYP_BATTGP]
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(emu_so) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "c_caller ok" in r.stdout, r.stdout + r.stderr
+    got = np.array([float(v) for v in r.stdout.splitlines()[0].split("grad")[1].split()])
+    assert np.all(np.abs(got - grad) <= 1e-5 * np.abs(grad) + 1e-7 * np.abs(grad).max()), (got, grad)
