@@ -31,7 +31,7 @@ def pytest_configure(config):
 
 # The driver runs the GPU suite with -x: what is most basic (and longest validated on the hardware) goes first, so that a
 # failure in a younger layer (adaptor, sharded driver, optional schedules) can not cut the core parity record short.
-GPU_ORDER = ["test_gpu_parity", "test_gpu_pins_and_sizes", "test_gpu_slab_layout", "test_gpu_adaptor", "test_gpu_sharded",
+GPU_ORDER = ["test_gpu_parity", "test_gpu_pins_and_sizes", "test_gpu_slab_layout", "test_gpu_adaptor", "test_gpu_sharded", "test_gpu_c_caller",
              "test_gpu_zz_optional_schedules"]
 
 

@@ -577,3 +577,4 @@ def test_unsorted_time_column_takes_the_general_wiener_path():
     ref = OracleGP(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, xt, y).fit()
     assert abs(e.fit(xt, y) - ref.lml) <= REL * abs(ref.lml)
     e.close()
+
