@@ -284,3 +284,26 @@ def test_a_time_limit_during_the_side_measurements_still_prints_the_record(tmp_p
         except (ProcessLookupError, FileNotFoundError):
             alive = False
         assert not alive, pid
+
+
+def test_ab_decision_tool_applies_the_rule(tmp_path):
+    """tools/decide_ab.py: > 2 % faster AND bit-identical -> promote at those sizes; differing bits or no gain -> delete"""
+    import subprocess
+
+    def w(name, rows):
+        (tmp_path / name).write_text("\n".join(json.dumps(r) for r in rows) + "\n")
+
+    w("sweep_la1.jsonl", [{"n": 4096, "fit_predict_ms": 3.7}, {"n": 16384, "fit_predict_ms": 32.0}])
+    w("sweep_la33.jsonl", [{"n": 4096, "fit_predict_ms": 3.9}, {"n": 16384, "fit_predict_ms": 29.0}])
+    w("sweep_la129.jsonl", [{"n": 4096, "fit_predict_ms": 3.69}, {"n": 16384, "fit_predict_ms": 31.9}])
+    w("bench_default.json", [{"experiments": {"runs": [{"n": 16384, "lookahead": 33, "fit_predict_ms": 29.1, "identical_to_default": True},
+                                                       {"n": 16384, "lookahead": 65, "fit_predict_ms": 25.0, "identical_to_default": False},
+                                                       {"n": 16384, "lookahead": 1, "fit_predict_ms": 32.0, "identical_to_default": True}]}}])
+    (tmp_path / "fill_rate.txt").write_text("matern32  N=131072: 4000 5500 5510  GB/s   median(2..) 5507\n")
+    (tmp_path / "fill_rate_table256.txt").write_text("matern32  N=131072: 4000 5900 5910  GB/s   median(2..) 5905\n")
+    (tmp_path / "fill_rate_mfma.txt").write_text("matern32  N=131072: 4000 5500 5510  GB/s   median(2..) 5520\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "decide_ab.py"), str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    promote, delete = r.stdout.split("promote:")[1].split("delete:")
+    assert "lookahead 33" in promote and "[16384]" in promote and "table256" in promote
+    assert "lookahead 65" in delete and "differing bits" in delete and "lookahead 129" in delete and "fill variant mfma" in delete

@@ -74,5 +74,6 @@ if has sharded; then
   timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras --sharded-grad --force-group > $OUT/sharded_n65536_rccl.json 2>> $OUT/sharded.err
   timeout 900 python bench.py --mode sharded --n 131072 --kernel battgp --steps 1 --warmup 0 --cpu-n 0 --no-extras > $OUT/sharded_n131072.json 2>> $OUT/sharded.err
 fi
+python tools/decide_ab.py $OUT > $OUT/ab_decision.txt 2>&1   # the promote / delete list of DESIGN.md section 8, from the files above
 stamp done
 ls -la $OUT
