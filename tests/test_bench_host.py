@@ -172,7 +172,7 @@ def test_side_measurements_cannot_take_the_bench_record_down(tmp_path):
 
     env = dict(os.environ, BGP_ROCPROFV3=str(tmp_path / "absent"))
     cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py", "--steps", "1", "--warmup", "0", "--size", "600",
-           "--extra-n", "500", "--cpu-n", "300"]
+           "--extra-n", "500", "--cpu-n", "300", "--experiments"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -230,7 +230,7 @@ def test_side_measurements_respect_their_time_budget():
     import subprocess
 
     cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py", "--steps", "1", "--warmup", "0",
-           "--size", "700", "--extra-n", "300", "--cpu-n", "0", "--side-budget-s", "0"]
+           "--size", "700", "--extra-n", "300", "--cpu-n", "0", "--side-budget-s", "0", "--experiments"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

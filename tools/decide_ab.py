@@ -6,7 +6,7 @@ the optional variants are either promoted or deleted the day they are measured:
     together with its knob.
 
     python tools/decide_ab.py gpurun_out/r03s          # reads sweep_la<word>.jsonl, sweep_small_la<word>.jsonl,
-                                                        # fill_rate*.txt, bench_default.json ("experiments")
+                                                        # ab_lookahead.jsonl, fill_rate*.txt, bench_default.json ("experiments")
 Prints one table per family and a final list "promote" / "delete".  Reads files only; needs no GPU."""
 import glob
 import json
@@ -40,13 +40,18 @@ def schedule_table(folder):
         for row in read_jsonl(path):
             ms.setdefault(la, {})[int(row["n"])] = min(float(row["fit_predict_ms"]), ms.get(la, {}).get(int(row["n"]), float("inf")))
     identical = {}
-    bench = os.path.join(folder, "bench_default.json")
+    runs = []
+    ab = os.path.join(folder, "ab_lookahead.jsonl")  # tools/ab_lookahead.py (gpu_session.sh, stage "slim")
+    if os.path.exists(ab):
+        runs += read_jsonl(ab)
+    bench = os.path.join(folder, "bench_default.json")  # bench.py --experiments files the same lines under "experiments"
     if os.path.exists(bench):
         for rec in read_jsonl(bench):
-            for run in (rec.get("experiments") or {}).get("runs", []):
-                la, n = int(run["lookahead"]), int(run["n"])
-                identical[(la, n)] = bool(run["identical_to_default"])
-                ms.setdefault(la, {}).setdefault(n, float(run["fit_predict_ms"]))
+            runs += (rec.get("experiments") or {}).get("runs", [])
+    for run in runs:
+        la, n = int(run["lookahead"]), int(run["n"])
+        identical[(la, n)] = bool(run["identical_to_default"]) and identical.get((la, n), True)
+        ms.setdefault(la, {}).setdefault(n, float(run["fit_predict_ms"]))
     return ms, identical
 
 

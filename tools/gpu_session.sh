@@ -7,7 +7,7 @@
 # Everything lands under gpurun_out/<tag>s/ ; copy what is to be judged into profiles/ afterwards
 # (python tools/pmc_summary.py gpurun_out/<tag>s/pmc131k <tag> 131072 matern32).
 TAG=${1:-r03}; shift
-STAGES=${*:-"tests bench stats pmc sweep slim system train fill sharded"}
+STAGES=${*:-"tests bench stats pmc sweep slim system train fill sharded optional"}
 REPO=$(pwd); OUT=$REPO/gpurun_out/${TAG}s; mkdir -p $OUT
 export TMPDIR=/tmp
 has() { [[ " $STAGES " == *" $1 "* ]]; }
@@ -44,6 +44,7 @@ if has slim; then
   for la in 1 33 65 97 129 193; do
     BGP_LA=$la BGP_SCHEME=1 BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 4096 8192 16384 24576 32768 40000 65536 > $OUT/sweep_la$la.jsonl 2>> $OUT/sweep_n.err
   done
+  timeout 600 python tools/ab_lookahead.py 3 4096 16384 40000 > $OUT/ab_lookahead.jsonl 2>> $OUT/sweep_n.err   # with the bit-identity flag
   for la in 1 129; do BGP_LA=$la BGP_ONLY=battgp timeout 300 python tools/sweep_n.py 9 1024 2048 4096 8192 > $OUT/sweep_small_la$la.jsonl 2>> $OUT/sweep_n.err; done
   (cd /tmp && BGP_LA=97 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl16k_slim -o tl -- \
      python $REPO/tools/profile_workload.py 16384 battgp 3 > $OUT/tl16k_slim.log 2>&1)
@@ -73,6 +74,11 @@ if has sharded; then
   timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras --sharded-grad > $OUT/sharded_n65536.json 2> $OUT/sharded.err
   timeout 600 python bench.py --mode sharded --n 65536 --kernel battgp --steps 1 --warmup 1 --cpu-n 0 --no-extras --sharded-grad --force-group > $OUT/sharded_n65536_rccl.json 2>> $OUT/sharded.err
   timeout 900 python bench.py --mode sharded --n 131072 --kernel battgp --steps 1 --warmup 0 --cpu-n 0 --no-extras > $OUT/sharded_n131072.json 2>> $OUT/sharded.err
+fi
+if has optional; then
+  stamp "optional schedules / fill variants through the test suite (child processes, xfail(strict=False))"
+  BGP_TEST_OPTIONAL=1 timeout 1500 python -m pytest tests/test_gpu_zz_optional_schedules.py -m gpu -q -rxX > $OUT/pytest_optional.log 2>&1
+  stamp "optional rc=$? $(tail -1 $OUT/pytest_optional.log)"
 fi
 python tools/decide_ab.py $OUT > $OUT/ab_decision.txt 2>&1   # the promote / delete list of DESIGN.md section 8, from the files above
 stamp done
