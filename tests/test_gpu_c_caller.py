@@ -11,7 +11,7 @@ from battgp_amd import synthetic  # noqa: E402
 from oracle import kernels as K  # noqa: E402
 
 
-def test_plain_c_caller_on_the_gpu(tmp_path):
+def test_plain_c_caller_on_the_gpu(tmp_path, request):
     """tests/cabi/c_caller.c - a C99 program that includes include/battgp.h and links libbattgp.so - on the GPU: the
     reference's known answers, argument errors, and LML + analytic gradient of a production-kernel problem against
     the oracle (the same program the CPU suite runs against the CPU build of the kernel sources)."""
@@ -21,6 +21,8 @@ def test_plain_c_caller_on_the_gpu(tmp_path):
     from battgp_amd import _lib
     from oracle.exact_gp import lml_and_grad
 
+    if request.config.getoption("--emu"):
+        pytest.skip("links the PRODUCT library: needs the GPU (the CPU suite runs the same program against the CPU build)")
     if shutil.which("gcc") is None:
         pytest.skip("no gcc on this box")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
