@@ -332,3 +332,14 @@ def test_optional_interior_paths_of_the_fill():
             if kid != "0":  # K0 takes it only where the sorted-time Wiener form applies: below the diagonal of a training fill
                 assert res[k][kid]["digest"] != res["default"][kid]["digest"], (k, kid)            # cross fill took the path
             assert res[k][kid]["factor_digest"] != res["default"][kid]["factor_digest"], (k, kid)  # and so did the training fill
+
+
+def test_index_arithmetic_beyond_2_pow_32_elements():
+    """tests/emu/huge_ld_check.py: small problems stored at a leading dimension of 2^25 (2^23) elements, so that every
+    kernel's ``row + col * ld`` passes 2^31 and 2^32 - the sharded device path end to end (fill, factor + pack, updates,
+    prediction, in-place inverse, gradient reduction), the MFMA GEMM in all four modes, the block copies and the blocked
+    Cholesky driver under every look-ahead word - in seconds, without an N > 46 341 problem"""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "huge_ld_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok: index arithmetic beyond 2^32 elements" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
