@@ -103,6 +103,7 @@ SIGNATURES = {
     "bgp_rowdot_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "bgp_var_finish_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_double, C.c_void_p]),
     "bgp_debug_clock_samples_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int, C.c_int]),
+    "bgp_debug_set_ld_pad": (C.c_int, [handle_p, C.c_int64]),
     "bgp_sync": (C.c_int, [handle_p]),
 }
 

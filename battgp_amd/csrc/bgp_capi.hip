@@ -768,6 +768,7 @@ int alloc_problem(bgp_handle* h, int64_t N, int D, int64_t Mride) {
   // columns of a tile in one HBM channel)
   int64_t lda = Npad + aug_need;
   if (lda >= 2048 && (lda % 512) == 0) lda += 64;
+  lda += h->ld_pad;
   int64_t W = BGP_W_FULL;
   int rc;
   if ((rc = choose_slab_width(h, Npad, lda, &W))) return rc;
@@ -1094,6 +1095,10 @@ void reset_logical(bgp_handle* h) {
   h->lookahead = fresh.lookahead;
   h->panel_mode = fresh.panel_mode;
   h->slab_req = fresh.slab_req;
+  if (h->ld_pad != 0) {  // (a padded buffer is not what a new handle would allocate)
+    free_problem(h);
+    h->ld_pad = 0;
+  }
   h->fitted = false;
   h->has_data = false;
   h->t_sorted = false;
@@ -1285,6 +1290,18 @@ int bgp_set_layout(bgp_handle* h, int64_t slab_width) {
     if (h->s_main) (void)hipStreamSynchronize(h->s_main);
     free_problem(h);
     h->slab_req = slab_width;
+  }
+  return 0;
+}
+
+int bgp_debug_set_ld_pad(bgp_handle* h, int64_t extra_rows) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (extra_rows < 0 || (extra_rows & 1)) return bgp_fail(h, -1, "bgp_debug_set_ld_pad: extra_rows must be even and >= 0");
+  if (extra_rows != h->ld_pad) {
+    if (h->s_main) (void)hipStreamSynchronize(h->s_main);
+    free_problem(h);
+    h->ld_pad = extra_rows;
   }
   return 0;
 }

@@ -76,6 +76,7 @@ struct bgp_handle {
   int lookahead = 1;
   int panel_mode = -1;   // 1: chain on the diagonal block + one deep TRSM-by-inverse GEMM; 0: 64-wide chain over all rows;
                          // -1 (default): 0 below Npad = 16384, 1 from there on (measured crossover)
+  int64_t ld_pad = 0;    // bgp_debug_set_ld_pad: unused rows appended to every column (index arithmetic at large strides on small problems)
   int64_t slab_req = 0;  // bgp_set_layout: 0 auto (full square if it fits, else slabs), -1 full square, > 0 width
   // problem
   int64_t N = 0, Npad = 0, lda = 0;

@@ -109,6 +109,11 @@ class ExactGPEngine:
         (~4 N (N + W) B, what lets N = 262 144 fit one MI355X), 0 = automatic (default)."""
         self._check(self._lib.bgp_set_layout(self._h, int(slab_width)), "bgp_set_layout")
 
+    def debug_set_ld_pad(self, extra_rows: int) -> None:
+        """Tests / diagnostics: unused rows appended to every column of the factor buffer from the next fit on
+        (``bgp_debug_set_ld_pad``): BASELINE-size element strides on a small problem."""
+        self._check(self._lib.bgp_debug_set_ld_pad(self._h, int(extra_rows)), "bgp_debug_set_ld_pad")
+
     def layout(self) -> tuple[int, int]:
         """(slab width in use, 0 = full square; bytes of the factor buffer)."""
         w, b = C.c_int64(0), C.c_int64(0)

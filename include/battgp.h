@@ -368,6 +368,13 @@ int bgp_var_finish_dev(bgp_handle* h, const double* Xq_dev, int64_t M, int D, co
  * Asynchronous (bgp_sync). */
 int bgp_debug_clock_samples_dev(bgp_handle* h, uint64_t* out_dev, int nsamp, int spin);
 
+/* Diagnostic / tests: `extra_rows` unused rows are appended to every column of the factor buffer from the next fit on
+ * (leading dimension N + 64 + riding rows + extra_rows; even, >= 0; 0 restores the default).  Small problems then address
+ * the buffer with the element strides of the BASELINE sizes (row + col * ld beyond 2^31 / 2^32), which is how the CPU
+ * suite checks the index arithmetic of the whole single-GPU path without an N > 46 341 problem
+ * (tests/emu/huge_ld_check.py).  Frees the resident problem; a pooled handle that is revived starts at 0 again. */
+int bgp_debug_set_ld_pad(bgp_handle* h, int64_t extra_rows);
+
 /* Wait for everything enqueued on the handle's streams. */
 int bgp_sync(bgp_handle* h);
 

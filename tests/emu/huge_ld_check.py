@@ -133,9 +133,62 @@ def building_blocks():
     eng.close()
 
 
+def engine_path():
+    """the single-GPU engine end to end with ``bgp_debug_set_ld_pad``: fit / fused fit+predict (query rows riding below the
+    matrix) / later predict / full covariance / residual checks / in-place-inverse gradient / refit, full square and
+    column slabs, at a leading dimension of ~2^23: the columns from 256 on lie beyond element 2^31, from 512 on beyond 2^32"""
+    from battgp_amd import synthetic
+    from battgp_amd.engine import ExactGPEngine
+    from oracle import kernels as K
+    from oracle.exact_gp import OracleGP, lml_and_grad
+
+    pad = 1 << 23
+    for kid, hyp, n, nb, slab, scheme in [(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, 600, 128, -1, 1), (K.KERNEL_MATERN32, synthetic.HYP_MATERN32, 450, 64, 128, 0),
+                                          (K.KERNEL_BATTGP, synthetic.HYP_BATTGP, 330, 128, 128, 1)]:
+        x, y = synthetic.make_cell_data(n, seed=88)
+        xq = synthetic.make_query(x, 37)
+        ref = OracleGP(kid, hyp, x, y).fit()
+        m_ref, v_ref = ref.predict(xq, clamp=False)
+        _, c_ref = ref.predict(xq[:9], full_cov=True)
+        _, g_ref = lml_and_grad(kid, hyp, x, y)
+        prior = hyp[1 if kid else 2]
+        e = ExactGPEngine(kid, hyp)
+        try:
+            e.set_options(nb_outer=nb, lookahead=1)
+            e.set_panel_scheme(scheme)
+            e.set_layout(slab)
+            e.debug_set_ld_pad(pad)
+            lml, mean, var = e.fit_predict(x, y, xq, min_var=-1.0)
+            width, nbytes = e.layout()
+            assert nbytes > 8 * (1 << 31), nbytes  # the buffer really spans more than 2^31 (N = 600: 2^32) elements
+            assert (width > 0) == (slab > 0)
+            lml_b = e.fit(x, y)
+            mean_b, var_b = e.predict(xq, min_var=-1.0)
+            for ll, mm, vv in ((lml, mean, var), (lml_b, mean_b, var_b)):
+                assert abs(ll - ref.lml) <= 1e-6 * abs(ref.lml), (ll, ref.lml)
+                assert np.linalg.norm(mm - m_ref) <= 1e-6 * np.linalg.norm(m_ref)
+                assert np.max(np.abs(vv - v_ref)) <= 1e-7 * prior
+            _, cov = e.predict_cov(xq[:9])
+            assert np.max(np.abs(cov - c_ref)) <= 1e-7 * prior
+            r_solve, r_llt = e.residuals(64)
+            assert r_solve < 1e-6 and r_llt < 1e-12, (r_solve, r_llt)
+            g = e.lml_grad()
+            assert np.all(np.abs(g - g_ref) <= 1e-5 * np.maximum(np.abs(g_ref), 1e-3 * np.abs(g_ref).max())), (g, g_ref)
+            mean_c, var_c = e.predict(xq, min_var=-1.0)  # the factor the gradient consumed is rebuilt
+            assert np.array_equal(mean_c, mean_b) and np.array_equal(var_c, var_b)
+            hyp2 = hyp.copy()
+            hyp2[1] *= 1.5
+            assert abs(e.refit(hyp2) - OracleGP(kid, hyp2, x, y).fit().lml) <= 1e-6 * abs(ref.lml)
+            print(f"  engine path, kernel {kid}, N {n}, nb {nb}, slab {slab}, scheme {scheme}, ld pad 2^23 ({nbytes / 2**30:.0f} GiB virtual): ok", flush=True)
+        finally:
+            e.close()
+
+
 fake_cuda_tensors()
+os.environ.setdefault("HIPEMU_MEM_GB", "100")  # the emulated device refuses allocations above this (virtual memory here)
 with installed(), warnings.catch_warnings():
     warnings.simplefilter("ignore")
     building_blocks()
     sharded_path()
+    engine_path()
     print("ok: index arithmetic beyond 2^32 elements", flush=True)
