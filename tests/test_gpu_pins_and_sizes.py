@@ -259,6 +259,50 @@ def test_n40000_battgp_natural_size():
     out["engine"].close()
 
 
+def _gradient_vs_lml_differences(e, hyp, rel_step=2e-4, rtol=2e-3):
+    """d lml / d log(theta_i) from bgp_lml_grad against central differences of the engine's own (oracle-checked) LML along
+    each log-parameter: 2 resident re-fits per parameter.  Not an independent pin (those are the scikit-learn / autograd
+    pins at small N) - the check that the in-place inverse and the reduction pass stay consistent with the value at a size
+    where the automatic defaults switch code paths."""
+    grad = e.lml_grad()
+    assert np.all(np.isfinite(grad))
+    for i in range(hyp.size):
+        hp, hm = hyp.copy(), hyp.copy()
+        hp[i] *= 1.0 + rel_step
+        hm[i] *= 1.0 - rel_step
+        fd = (e.refit(hp) - e.refit(hm)) / (2.0 * rel_step)  # d lml / d log theta_i
+        an = grad[i] * hyp[i]
+        # (central differences of a value that is itself good to ~1e-10 relative: an absolute floor from that noise)
+        assert abs(fd - an) <= rtol * abs(an) + 2e-9 * abs(e.lml) / rel_step + 1e-3, (i, fd, an)
+    e.refit(hyp)
+    return grad
+
+
+def test_n40000_gradient_at_the_natural_size():
+    """BASELINE config 2's size: the in-place-inverse gradient under the automatic defaults (panel scheme 1, NB = 1024,
+    full square) and in column slabs - consistent with differences of the LML, identical between the two layouts up to
+    the summation order of the reduction pass, and the factor comes back bit for bit."""
+    n = 40000
+    x, y = synthetic.make_cell_data(n)
+    xq = synthetic.make_query(x, 300)
+    hyp = synthetic.HYP_BATTGP.copy()
+    e = ExactGPEngine(K.KERNEL_BATTGP, hyp)
+    try:
+        lml = e.fit(x, y)
+        mean, var = e.predict(xq, min_var=-1.0)
+        g_full = _gradient_vs_lml_differences(e, hyp)
+        mean2, var2 = e.predict(xq, min_var=-1.0)
+        assert e.lml == lml and np.array_equal(mean, mean2) and np.array_equal(var, var2)
+        e.set_layout(8192)
+        assert e.fit(x, y) == lml and e.layout()[0] == 8192
+        g_slab = e.lml_grad()
+        assert np.allclose(g_slab, g_full, rtol=1e-9), (g_slab, g_full)
+        mean3, var3 = e.predict(xq, min_var=-1.0)
+        assert np.array_equal(mean, mean3) and np.array_equal(var, var3)
+    finally:
+        e.close()
+
+
 def test_n131072_matern_natural_size_and_layouts():
     """BASELINE config 3 at full size: N = 131 072, Matern-3/2 + noise; plus the column-slab layout of the same
     problem, which must reproduce LML, mean and variance bit for bit."""
