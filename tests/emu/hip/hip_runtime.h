@@ -129,7 +129,10 @@ static inline hipError_t hipMalloc(void** p, size_t bytes) {
   const char* lim = getenv("HIPEMU_MEM_GB");
   if (bytes > ((size_t)(lim ? atoi(lim) : 6) << 30)) return hipErrorOutOfMemory;
   if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
-  memset(q, 0xA5, bytes < ((size_t)1 << 28) ? bytes : ((size_t)1 << 28));  // fresh device memory is NOT zero
+  // fresh device memory is NOT zero: 0xA5 bytes (a finite -1e-128 in fp64) by default; HIPEMU_POISON=ff makes every
+  // never-written double a NaN, so that anything that lets a don't-care entry reach a result shows up at once
+  static const int poison = getenv("HIPEMU_POISON") ? (int)strtol(getenv("HIPEMU_POISON"), nullptr, 16) : 0xA5;
+  memset(q, poison, bytes < ((size_t)1 << 28) ? bytes : ((size_t)1 << 28));
   *p = q;
   return hipSuccess;
 }

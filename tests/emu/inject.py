@@ -79,6 +79,18 @@ def fake_cuda_tensors():
 
     for name in ("zeros", "empty", "full", "ones", "tensor", "as_tensor", "arange", "randn", "rand", "empty_like", "zeros_like", "linspace", "eye"):
         setattr(torch, name, strip(getattr(torch, name)))
+    if os.environ.get("HIPEMU_POISON", "").lower() == "ff":
+        # "device" tensors the drivers allocate uninitialised (torch.empty on the host: usually fresh zero pages) become NaN,
+        # like the CPU build's hipMalloc under the same switch - up to 2^28 elements (the huge-stride checks stay virtual)
+        plain_empty = torch.empty
+
+        def poisoned_empty(*a, **k):
+            t = plain_empty(*a, **k)
+            if t.is_floating_point() and 0 < t.numel() <= (1 << 28):
+                t.fill_(float("nan"))
+            return t
+
+        torch.empty = poisoned_empty
     real_to = torch.Tensor.to
 
     def to(self, *a, **k):

@@ -40,6 +40,18 @@ def test_random_sharded_problems_match_the_oracle_on_the_cpu_build():
     derandomised, in a process of its own (torch's CUDA entry points are faked there)"""
     import subprocess
 
+    # HIPEMU_POISON=ff: every never-written double of the "device" memory (hipMalloc of the CPU build, torch.empty of the
+    # driver) is a NaN instead of whatever fresh pages hold - a don't-care entry that reached a result would show
     r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "sharded_fuzz.py"), "40", "330", "derandomize"],
-                       capture_output=True, text=True, timeout=900)
+                       env=dict(os.environ, HIPEMU_POISON="ff"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok: 40 sharded problems" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_random_problems_with_nan_poisoned_device_memory():
+    """the engine's property under HIPEMU_POISON=ff (fresh device memory = NaN): the strict upper triangles, padding rows
+    and workspace tails the kernels treat as don't-care must never contaminate a result"""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "fuzz_campaign.py"), "60", "200", "20260930"],
+                       env=dict(os.environ, HIPEMU_POISON="ff"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok: 60 problems" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
