@@ -35,7 +35,7 @@ def build(sanitize=False, force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OUT_DIR, exist_ok=True)
     kind = "asan" if sanitize == "asan" else ("ubsan" if sanitize else "")
     lib = os.path.join(OUT_DIR, f"libbattgp_emu_{kind}.so" if kind else "libbattgp_emu.so")
-    deps = SOURCES + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "bgp_internal.h"), os.path.join(ROOT, "include", "battgp.h")]
+    deps = SOURCES + [os.path.abspath(__file__), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "bgp_internal.h"), os.path.join(ROOT, "include", "battgp.h")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(d) for d in deps):
         return lib
     objs = []
@@ -53,6 +53,17 @@ def build(sanitize=False, force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(obj)
+    # thread-local markers linked around the two kernel objects: what lies between them in a thread's TLS block is the
+    # kernels' LDS (their `static thread_local` arrays), which HIPEMU_POISON=ff fills before every workgroup (hipemu.cpp)
+    marks = []
+    for name in ("hipemu_lds_begin", "hipemu_lds_end"):
+        msrc, mobj = os.path.join(OUT_DIR, name + ".cpp"), os.path.join(OUT_DIR, name + (f".{kind}.o" if kind else ".o"))
+        with open(msrc, "w") as f:
+            f.write(f"thread_local char {name}[64];\n")
+        subprocess.run([_compiler(), "-std=c++17", "-O1", "-fPIC", "-c", msrc, "-o", mobj], check=True)
+        marks.append(mobj)
+    kernels = [o for o in objs if "bgp_fill" in o or "bgp_linalg" in o]
+    objs = [marks[0], *kernels, marks[1], *[o for o in objs if o not in kernels]]
     san_link = []
     if kind:  # the sanitizer runtime as a shared object next to the compiler, found through an rpath
         rt_dir = os.path.dirname(sanitizer_runtime(kind))

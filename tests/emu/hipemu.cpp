@@ -49,6 +49,9 @@ hipemu_switch:
 #endif
 #endif
 
+extern thread_local char hipemu_lds_begin[64];  // tests/emu/build_emu.py links these two around the kernel objects
+extern thread_local char hipemu_lds_end[64];
+
 namespace hipemu {
 
 double now_ms() {
@@ -165,7 +168,30 @@ uint64_t wave_arrive() {
   return g;
 }
 
+// LDS of the kernels = the `static thread_local` arrays of the two kernel translation units, which the build links between
+// the two marker objects below: [hipemu_lds_begin, bgp_fill, bgp_linalg, hipemu_lds_end].  A worker thread is created per
+// launch, so those arrays start as ZEROS for nearly every workgroup - kinder than the GPU, where LDS holds whatever the
+// previous workgroup left.  HIPEMU_POISON=ff fills them with 0xFF (fp64 NaN, int -1) before every workgroup: a kernel that
+// reads LDS it has not written shows up.
+void poison_lds() {
+  static const bool on = [] {
+    const char* e = getenv("HIPEMU_POISON");
+    return e && (strtol(e, nullptr, 16) & 0xff) == 0xff;
+  }();
+  if (!on) return;
+  char* lo = hipemu_lds_begin + sizeof(hipemu_lds_begin);
+  char* hi = hipemu_lds_end;
+  if (hi < lo || hi - lo > (ptrdiff_t)(64 << 20)) {
+    fprintf(stderr, "hipemu: LDS markers out of order (%p .. %p): link order changed?\n", (void*)lo, (void*)hi);
+    abort();
+  }
+  static std::atomic<bool> said{false};
+  if (!said.exchange(true)) fprintf(stderr, "hipemu: LDS poison on (%zu bytes of kernel LDS arrays per worker thread)\n", (size_t)(hi - lo));
+  memset(lo, 0xFF, (size_t)(hi - lo));
+}
+
 void run_block(Block* b, dim3 grid, dim3 block, dim3 bid, const std::function<void()>& body) {
+  poison_lds();
   const int nt = (int)(block.x * block.y * block.z);
   b->nthreads = b->live = nt;
   b->arrived = 0;
