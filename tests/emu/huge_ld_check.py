@@ -186,7 +186,9 @@ def engine_path():
 
 fake_cuda_tensors()
 os.environ.setdefault("HIPEMU_MEM_GB", "100")  # the emulated device refuses allocations above this (virtual memory here)
-with installed(), warnings.catch_warnings():
+# --ubsan: the UndefinedBehaviorSanitizer build (signed overflow of a 32-bit intermediate aborts even where the wrapped value
+# would happen to be harmless)
+with installed(sanitize="--ubsan" in sys.argv), warnings.catch_warnings():
     warnings.simplefilter("ignore")
     building_blocks()
     sharded_path()
