@@ -343,3 +343,12 @@ def test_index_arithmetic_beyond_2_pow_32_elements():
 
     r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "huge_ld_check.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok: index arithmetic beyond 2^32 elements" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_lds_poison_reaches_unwritten_shared_arrays():
+    """self-test of HIPEMU_POISON=ff (tests/emu/lds_poison_selftest.py): a probe kernel that reads a __shared__ array it
+    never wrote sees zeros in the plain CPU build and NaN under the switch - the poisoned runs of the suite are not vacuous"""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "lds_poison_selftest.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok: the LDS poison reaches" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
