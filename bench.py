@@ -109,7 +109,11 @@ def kernel_setup(name: str):
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle = port of the reference algorithm; checker code timed as a baseline, never the product)
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline(kernel_name: str, n_cpu: int, m: int, n_second: int = 0, budget_s: float = 150.0) -> dict:
+OPENBLAS_POTRF_LIMIT = 32768  # scipy's / numpy's OpenBLAS dpotrf of this image segfaults from N = 2^15 on (seen at 32 700 / 32 800;
+                              # 30 000 is fine; torch's MKL is unaffected) - never call it there
+
+
+def cpu_baseline(kernel_name: str, n_cpu: int, m: int, n_second: int = 0, budget_s: float = 150.0, progress=None) -> dict:
     """The oracle's dense algorithm on the host cores with its phases timed separately: threaded numpy fill, LAPACK
     dpotrf, triangular solves + posterior.  The factorisation is timed with BOTH LAPACKs of this image - scipy's
     OpenBLAS (built for at most 64 threads, whatever the host has) and torch's CPU LAPACK (MKL, `torch.get_num_threads()`
@@ -139,18 +143,27 @@ def cpu_baseline(kernel_name: str, n_cpu: int, m: int, n_second: int = 0, budget
         sigma[np.diag_indices(n)] += K.noise(hyp)
         t1 = time.perf_counter()
         potrf = {}
-        if torch is not None and both:
+        chol = None
+        big = n >= OPENBLAS_POTRF_LIMIT - 1024  # (margin: the library's limit was not bisected below 32 700)
+        if torch is not None and (both or big):
             try:
                 tt = time.perf_counter()
                 lt = torch.linalg.cholesky(torch.from_numpy(sigma))
                 potrf["torch_cpu_lapack"] = {"seconds": time.perf_counter() - tt, "threads": torch_threads}
+                if big:
+                    chol = lt.numpy()  # this factor feeds the solves: OpenBLAS must not see a matrix of this size
                 del lt
             except Exception as exc:  # noqa: BLE001 - the scipy path below is the one the solves use
                 potrf["torch_cpu_lapack"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
-        tt = time.perf_counter()
-        chol, info = sla.lapack.dpotrf(sigma, lower=1, clean=0, overwrite_a=1)
-        assert info == 0
-        potrf["scipy_openblas"] = {"seconds": time.perf_counter() - tt, "threads": int(blas_threads)}
+        if not big:
+            tt = time.perf_counter()
+            chol, info = sla.lapack.dpotrf(sigma, lower=1, clean=0, overwrite_a=1)
+            assert info == 0
+            potrf["scipy_openblas"] = {"seconds": time.perf_counter() - tt, "threads": int(blas_threads)}
+        else:
+            potrf["scipy_openblas"] = {"skipped": f"OpenBLAS dpotrf of this image segfaults for N >= {OPENBLAS_POTRF_LIMIT}; torch's LAPACK factors this sample"}
+            if chol is None:
+                raise RuntimeError("no LAPACK available for a sample of this size (torch missing or its factorisation failed)")
         t2 = time.perf_counter()
         z = sla.solve_triangular(chol, y, lower=True, check_finite=False)
         kxs = K.kernel_matrix(kid, hyp, x, xq)
@@ -191,6 +204,8 @@ def cpu_baseline(kernel_name: str, n_cpu: int, m: int, n_second: int = 0, budget
                   f"its build-time cap, host has {os.cpu_count()} CPUs) and torch CPU LAPACK ({torch_threads} threads), faster one counted "
                   f"({main['potrf_lapack_used']})",
     }
+    if progress is not None:
+        progress(rec)  # the first sample is safe whatever the second one does
     if n_second > n_cpu:
         est = main["seconds"] * (n_second / n_cpu) ** 3 * (2.0 if len(main["potrf_by_lapack"]) > 1 else 1.0)
         if est <= budget_s:
@@ -200,6 +215,8 @@ def cpu_baseline(kernel_name: str, n_cpu: int, m: int, n_second: int = 0, budget
                 rec["second_sample"] = {"n": n_second, "error": f"{type(exc).__name__}: {exc}"[:200]}
         else:
             rec["second_sample"] = {"n": n_second, "skipped": f"estimated {est:.0f} s from the N={n_cpu} rate, budget {budget_s:.0f} s"}
+        if progress is not None:
+            progress(rec)
     return rec
 
 
@@ -595,15 +612,33 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
 
 
 def host_baseline(out, args) -> None:
-    """out["cpu_baseline"]: the oracle's dense path on this box's host cores (bounded samples); never raises."""
-    if "cpu_baseline" in out:
+    """out["cpu_baseline"]: the oracle's dense path on this box's host cores (bounded samples), measured in a CHILD process
+    (`bench.py --mode cpu_baseline`) that prints its record after every sample: a LAPACK that crashes on a large matrix
+    (this image's OpenBLAS dpotrf does from N = 32 768 on) or runs away costs at most the later sample, never the GPU
+    record.  Never raises."""
+    if "cpu_baseline" in out or args.cpu_n <= 0:
         return
-    if args.cpu_n <= 0:
-        return
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "cpu_baseline", "--kernel", args.kernel, "--m", str(args.m),
+           "--cpu-n", str(args.cpu_n), "--cpu-n2", str(args.cpu_n2), "--cpu-budget-s", str(args.cpu_budget_s)]
+    rec, note = None, ""
     try:
-        out["cpu_baseline"] = cpu_baseline(args.kernel, args.cpu_n, args.m, args.cpu_n2, args.cpu_budget_s)
+        r = run_child(cmd, args.cpu_budget_s + 240.0)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"cpu_baseline"')]
+        if lines:
+            rec = json.loads(lines[-1])["cpu_baseline"]
+        if r.returncode != 0:
+            note = f"child ended with rc {r.returncode} after {len(lines)} record(s): {r.stderr[-200:]}"
     except Exception as exc:  # noqa: BLE001 - the GPU record is printed whatever happens to the host-side sample
-        out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"[:300]}
+        note = f"{type(exc).__name__}: {exc}"[:300]
+        so = getattr(exc, "stdout", None) or ""
+        lines = [ln for ln in (so if isinstance(so, str) else so.decode(errors="replace")).splitlines() if ln.startswith('{"cpu_baseline"')]
+        if lines:
+            rec = json.loads(lines[-1])["cpu_baseline"]
+    if rec is None:
+        rec = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {note}"[:300]}
+    elif note:
+        rec["child_note"] = note
+    out["cpu_baseline"] = rec
 
 
 def schedule_experiments(limit_s: float = 150.0):
@@ -687,7 +722,7 @@ def main() -> None:
                          "rejects --n as an ambiguous prefix of its own options")
     ap.add_argument("--m", type=int, default=300, help="query points (battgp_full.py:98)")
     ap.add_argument("--kernel", default="matern32", choices=["battgp", "matern32"])
-    ap.add_argument("--mode", default="cells", choices=["cells", "sharded"])
+    ap.add_argument("--mode", default="cells", choices=["cells", "sharded", "cpu_baseline"])
     ap.add_argument("--nb", type=int, default=-1, help="outer panel width override")
     ap.add_argument("--lookahead", type=int, default=-1, help="bits 0-2: look-ahead depth (0 off, 1 default); +8: panel-stream updates ordered before rest(k); +16: no atomic epilogue")
     ap.add_argument("--panel-scheme", type=int, default=-1, help="0 = 64-wide chain over all rows, 1 = diagonal-block chain + one deep TRSM GEMM (default)")
@@ -721,6 +756,10 @@ def main() -> None:
 
     signal.signal(signal.SIGTERM, _on_term)
     signal.signal(signal.SIGINT, _on_term)
+    if args.mode == "cpu_baseline":  # child of host_baseline(): host cores only, one JSON line per finished sample
+        cpu_baseline(args.kernel, args.cpu_n, args.m, args.cpu_n2, args.cpu_budget_s,
+                     progress=lambda rec: print(json.dumps({"cpu_baseline": rec}), flush=True))
+        return
     if args.force_group:
         os.environ["BGP_FORCE_GROUP"] = "1"
 

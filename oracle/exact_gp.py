@@ -38,6 +38,20 @@ MAX_TRIES = 3  # linear_operator.settings.cholesky_max_tries default
 MIN_VARIANCE_FP64 = 1e-10  # gpytorch.settings.min_variance, fp64 default
 
 
+OPENBLAS_POTRF_LIMIT = 32768 - 1024  # this image's OpenBLAS (scipy's and numpy's) dpotrf segfaults from N = 2^15 on (seen at
+                                     # 32 700; 30 000 is fine): from here on the factorisation goes through torch's LAPACK
+
+
+def _dpotrf_lower(a: np.ndarray, overwrite: bool):
+    """``(L, info)`` like ``scipy.linalg.lapack.dpotrf(a, lower=1, clean=1)``"""
+    if a.shape[0] < OPENBLAS_POTRF_LIMIT:
+        return sla.lapack.dpotrf(a, lower=1, clean=1, overwrite_a=int(overwrite))
+    import torch
+
+    fac, info = torch.linalg.cholesky_ex(torch.from_numpy(a))
+    return fac.numpy(), int(info)
+
+
 def psd_safe_cholesky(a: np.ndarray, jitter: float = JITTER_FP64, max_tries: int = MAX_TRIES):
     """Lower Cholesky factor with GPyTorch's jitter ladder.
 
@@ -48,14 +62,14 @@ def psd_safe_cholesky(a: np.ndarray, jitter: float = JITTER_FP64, max_tries: int
     a = np.asarray(a, dtype=np.float64)
     if not np.all(np.isfinite(a)):
         raise NotPSDError("matrix contains NaN/inf")
-    c, info = sla.lapack.dpotrf(a, lower=1, clean=1, overwrite_a=0)
+    c, info = _dpotrf_lower(a, overwrite=False)
     if info == 0:
         return c, 0.0
     for i in range(max_tries):
         jit = jitter * (10.0**i)
         aj = a.copy()
         aj[np.diag_indices_from(aj)] += jit
-        c, info = sla.lapack.dpotrf(aj, lower=1, clean=1, overwrite_a=1)
+        c, info = _dpotrf_lower(aj, overwrite=True)
         if info == 0:
             warnings.warn(
                 f"A not p.d., added jitter of {jit:.1e} to the diagonal", NumericalWarning

@@ -243,3 +243,23 @@ def test_lml_gradient_pinned_by_torch_autograd(golden_dir, name, n):
     want = g[p + "grad"]
     assert abs(lml - g[p + "lml"]) <= 1e-9 * abs(g[p + "lml"])
     assert np.all(np.abs(grad - want) <= 1e-6 * np.abs(want) + 1e-9 * np.abs(want).max()), (grad, want)
+
+
+def test_large_matrix_factorisation_route(monkeypatch):
+    """this image's OpenBLAS dpotrf (scipy's and numpy's) segfaults from N = 32 768 on, so the oracle factors larger matrices
+    through torch's LAPACK: same factor, same failure report, same jitter ladder (forced here at a small size)"""
+    import oracle.exact_gp as og
+
+    rng = np.random.default_rng(0)
+    g = rng.normal(size=(60, 60))
+    a = g @ g.T + 60 * np.eye(60)
+    l_scipy, info_s = og._dpotrf_lower(a.copy(), overwrite=False)
+    monkeypatch.setattr(og, "OPENBLAS_POTRF_LIMIT", 1)
+    l_torch, info_t = og._dpotrf_lower(a.copy(), overwrite=False)
+    assert info_s == info_t == 0 and np.allclose(l_scipy, l_torch, rtol=1e-13, atol=1e-13) and np.all(np.triu(l_torch, 1) == 0)
+    assert og._dpotrf_lower(-np.eye(4), overwrite=False)[1] > 0
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert og.psd_safe_cholesky(np.ones((4, 4)))[1] == 1e-8
+    with pytest.raises(NotPSDError):
+        og.psd_safe_cholesky(-np.eye(3))
