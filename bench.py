@@ -590,11 +590,13 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
         out["extra_configs"] = [e for e in extras if e]
         trim_pool(local_rank)  # the children below need the HBM
         # required field before optional evidence: the host-side baseline comes ahead of the profiler passes and the A/B
-        host_baseline(out, args)
+        # three profiler passes of one fit+predict each (+ process start): the step time is the best estimate of a pass
+        pass_s = 3.0 * (elapsed / args.steps) + 30.0
+        # the first CPU sample is a required field; the second (N = 40 000) is optional and only gets what the side budget
+        # has left once the profiler passes are paid for
+        host_baseline(out, args, second_budget_s=min(args.cpu_budget_s, remaining() - (0.0 if args.no_pmc else 3.0 * pass_s) - 30.0))
         if not args.no_pmc:
-            # three passes of one fit+predict each (+ process start): the step time is the best estimate of a pass
-            pass_s = 3.0 * (elapsed / args.steps) + 30.0
-            live = side("pmc_live", lambda: pmc_live(n, args.kernel, m, limit_s=max(60.0, min(240.0, remaining() / 3.0))), 3.0 * pass_s)
+            live = side("pmc_live", lambda: pmc_live(n, args.kernel, m, limit_s=max(60.0, min(180.0, remaining() / 3.0))), 3.0 * pass_s)
             out["pmc_live"] = live
             if live and live.get("hbm_bytes_per_dispatch"):
                 out["roofline"]["traffic"] = live["hbm_bytes_per_dispatch"]
@@ -611,18 +613,19 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
     return out
 
 
-def host_baseline(out, args) -> None:
+def host_baseline(out, args, second_budget_s=None) -> None:
     """out["cpu_baseline"]: the oracle's dense path on this box's host cores (bounded samples), measured in a CHILD process
     (`bench.py --mode cpu_baseline`) that prints its record after every sample: a LAPACK that crashes on a large matrix
     (this image's OpenBLAS dpotrf does from N = 32 768 on) or runs away costs at most the later sample, never the GPU
     record.  Never raises."""
     if "cpu_baseline" in out or args.cpu_n <= 0:
         return
+    budget = args.cpu_budget_s if second_budget_s is None else max(0.0, float(second_budget_s))
     cmd = [sys.executable, os.path.abspath(__file__), "--mode", "cpu_baseline", "--kernel", args.kernel, "--m", str(args.m),
-           "--cpu-n", str(args.cpu_n), "--cpu-n2", str(args.cpu_n2), "--cpu-budget-s", str(args.cpu_budget_s)]
+           "--cpu-n", str(args.cpu_n), "--cpu-n2", str(args.cpu_n2 if budget > 0 else 0), "--cpu-budget-s", str(budget)]
     rec, note = None, ""
     try:
-        r = run_child(cmd, args.cpu_budget_s + 240.0)
+        r = run_child(cmd, budget + 240.0)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"cpu_baseline"')]
         if lines:
             rec = json.loads(lines[-1])["cpu_baseline"]
@@ -732,7 +735,7 @@ def main() -> None:
     ap.add_argument("--cpu-budget-s", type=float, default=150.0)
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (steady fill, memset ceiling, N = 40 000 extra config)")
-    ap.add_argument("--side-budget-s", type=float, default=480.0,
+    ap.add_argument("--side-budget-s", type=float, default=420.0,
                     help="time budget of ALL side measurements after the timed region (steady fill, extra configuration, PMC passes, "
                          "schedule A/B); one that no longer fits is skipped and listed under side_measurement_errors")
     ap.add_argument("--extra-n", type=int, default=40000, help="size of the extra configuration measured beside the headline (BASELINE configs[1]: 40 000, the reference kernel; 0 = skip)")
