@@ -19,6 +19,8 @@ from inject import installed  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16400
 want_grad = "--no-grad" not in sys.argv
+# --engine-grad g0,g1,...: skip the engine (hours at N = 32 800) and compare the oracle's gradient with these printed values
+given = next((np.array([float(v) for v in a.split("=", 1)[1].split(",")]) for a in sys.argv if a.startswith("--engine-grad=")), None)
 
 from battgp_amd import synthetic  # noqa: E402
 from battgp_amd.engine import ExactGPEngine  # noqa: E402
@@ -36,6 +38,8 @@ with installed(), warnings.catch_warnings():
     print(f"oracle N={n}: {time.time() - t0:.0f} s, lml {ref.lml:.6f}", flush=True)
     e = ExactGPEngine(K.KERNEL_BATTGP, hyp)  # no option set: scheme, panel width and layout are the automatic ones
     try:
+        if given is not None:
+            raise StopIteration
         t0 = time.time()
         lml, mean, var = e.fit_predict(x, y, xq, min_var=-1.0)
         print(f"engine fit+predict: {time.time() - t0:.0f} s, lml rel {abs(lml - ref.lml) / abs(ref.lml):.1e}, "
@@ -51,15 +55,17 @@ with installed(), warnings.catch_warnings():
             g = e.lml_grad()
             print(f"engine gradient: {time.time() - t0:.0f} s {g}", flush=True)
             # oracle gradient without forming the N x N derivative matrices at once: 1/2 tr((alpha alpha^T - Sigma^-1) dK)
-            import scipy.linalg as sla
+            import torch  # (this image's OpenBLAS - scipy's and numpy's - segfaults in level-3 routines from N = 32 768 on: MKL)
 
             from oracle.exact_gp import kernel_derivatives
 
             t0 = time.time()
-            linv = sla.solve_triangular(ref.L, np.eye(n), lower=True, overwrite_b=True)
+            linv = torch.linalg.solve_triangular(torch.from_numpy(ref.L), torch.eye(n, dtype=torch.float64), upper=False)
             w = -(linv.T @ linv)
             del linv
-            w += np.outer(ref.alpha, ref.alpha)
+            w = w.numpy()
+            for i0 in range(0, n, 4096):  # + alpha alpha^T, block-wise (elementwise only)
+                w[i0:i0 + 4096] += ref.alpha[i0:i0 + 4096, None] * ref.alpha[None, :]
             g_ref = np.zeros(hyp.size)
             g_ref[0] = 0.5 * np.trace(w)
             blk = 2048
@@ -74,6 +80,26 @@ with installed(), warnings.catch_warnings():
             mean3, var3 = e.predict(xq, min_var=-1.0)  # the factor comes back bit for bit
             assert np.array_equal(mean3, mean2) and np.array_equal(var3, var2)
             print("factor restored after the gradient: ok", flush=True)
+    except StopIteration:
+        import torch
+
+        from oracle.exact_gp import kernel_derivatives
+
+        t0 = time.time()
+        linv = torch.linalg.solve_triangular(torch.from_numpy(ref.L), torch.eye(n, dtype=torch.float64), upper=False)
+        w = -(linv.T @ linv)
+        del linv
+        w = w.numpy()
+        for i0 in range(0, n, 4096):
+            w[i0:i0 + 4096] += ref.alpha[i0:i0 + 4096, None] * ref.alpha[None, :]
+        g_ref = np.zeros(hyp.size)
+        g_ref[0] = 0.5 * np.trace(w)
+        for i0 in range(0, n, 2048):
+            for i, dk in enumerate(kernel_derivatives(K.KERNEL_BATTGP, hyp, x[i0:i0 + 2048], x)):
+                g_ref[1 + i] += 0.5 * np.sum(w[i0:i0 + 2048] * dk)
+        rel = np.abs(given - g_ref) / np.abs(g_ref)
+        print(f"oracle gradient: {time.time() - t0:.0f} s {g_ref}\nengine (as printed by the earlier run) vs oracle, per component: {rel}", flush=True)
+        assert np.all(rel <= 1e-6)
     finally:
         e.close()
     print(f"ok: automatic defaults at N = {n}", flush=True)
