@@ -40,6 +40,7 @@ SIGNATURES = {
         [handle_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, c_double_p, c_double_p, C.c_void_p, C.c_void_p, C.c_double],
     ),
     "bgp_lml_grad": (C.c_int, [handle_p, c_double_p, C.c_int]),
+    "bgp_set_keep_factor": (C.c_int, [handle_p, C.c_int]),
     "bgp_predict": (C.c_int, [handle_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_double]),
     "bgp_predict_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double]),
     "bgp_predict_cov": (C.c_int, [handle_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
@@ -108,8 +109,9 @@ SIGNATURES = {
 }
 
 # indices of bgp_phase_times (BGP_T_* in battgp.h)
-T_H2D, T_FILL, T_POTRF, T_SOLVE, T_CROSS, T_VAR, T_D2H, T_TRAIL, T_TRAIL_FLOP, T_FILL_BYTES, T_TRAIL_LAUNCHES, T_TRAIL_UNION = range(12)
-T_COUNT = 12
+(T_H2D, T_FILL, T_POTRF, T_SOLVE, T_CROSS, T_VAR, T_D2H, T_TRAIL, T_TRAIL_FLOP, T_FILL_BYTES, T_TRAIL_LAUNCHES, T_TRAIL_UNION,
+ T_GRAD, T_RESTORE) = range(14)
+T_COUNT = 14
 
 _lib = None
 

@@ -692,7 +692,14 @@ int backward_driver(bgp_handle* h, hipStream_t st) {
   return 0;
 }
 
+void free_keep(bgp_handle* h) {
+  dev_free(h, &h->dA_keep, h->A_keep_doubles);
+  h->A_keep_doubles = 0;
+  h->keep_valid = false;
+}
+
 void free_problem(bgp_handle* h) {
+  free_keep(h);
   dev_free(h, &h->dA, h->A_doubles);
   h->A_doubles = 0;
   h->slabW = BGP_W_FULL;
@@ -802,8 +809,10 @@ int fit_resident(bgp_handle* h, double* lml_out, double* jitter_out, int64_t Mri
   const SlabView V = h->view();
   h->fitted = false;
   h->factor_consumed = false;  // the storage is refilled below
+  h->keep_valid = false;
   h->LinvAll_nb = 0;
   h->times[BGP_T_FILL] = h->times[BGP_T_POTRF] = h->times[BGP_T_CROSS] = 0.0;
+  h->times[BGP_T_RESTORE] = 0.0;
   const int64_t ride_rows = round_up(Mride, 64);
   if (BGP_AUG + ride_rows > h->aug_cap) return bgp_fail(h, -1, "internal: no room for %lld riding rows", (long long)Mride);
   h->aug_used = BGP_AUG + ride_rows;
@@ -900,10 +909,28 @@ int ensure_alpha(bgp_handle* h) {
 // loops re-fit with new hyper-parameters before every gradient anyway: src/gp/training.py:39-41).
 int ensure_factor(bgp_handle* h) {
   if (!h->factor_consumed) return 0;
+  // bookkeeping of the FIT stays what the fit measured: what is spent here is reported in its own slot
+  (void)collect_phases(h);
+  double saved[BGP_T_COUNT];
+  memcpy(saved, h->times, sizeof(saved));
+  if (h->keep_valid && h->dA_keep && h->A_keep_doubles == h->A_doubles) {
+    // bgp_set_keep_factor: the storage as bgp_lml_grad found it (factor, z^T row, riding rows) comes back by one copy;
+    // z, alpha, the LML, the tile and panel inverses were never touched by the gradient
+    PhaseTimer t(h, h->s_main, BGP_T_RESTORE);
+    BGP_HIP(h, hipMemcpyAsync(h->dA, h->dA_keep, (size_t)h->A_doubles * sizeof(double), hipMemcpyDeviceToDevice, h->s_main));
+    int rc = t.stop();
+    if (rc) return rc;
+    h->factor_consumed = false;
+    return 0;
+  }
   const bool alpha_was_ready = h->alpha_ready;  // alpha lives in its own vector and stays what it was
   int rc = fit_resident(h, nullptr, nullptr, 0);
   if (rc) return rc;
   h->alpha_ready = alpha_was_ready;
+  (void)collect_phases(h);
+  const double spent = h->times[BGP_T_FILL] + h->times[BGP_T_POTRF] + h->times[BGP_T_SOLVE];
+  memcpy(h->times, saved, sizeof(saved));
+  h->times[BGP_T_RESTORE] = spent;
   return 0;
 }
 
@@ -1095,6 +1122,8 @@ void reset_logical(bgp_handle* h) {
   h->lookahead = fresh.lookahead;
   h->panel_mode = fresh.panel_mode;
   h->slab_req = fresh.slab_req;
+  h->keep_factor = fresh.keep_factor;
+  free_keep(h);  // (a new handle holds no second factor-sized buffer)
   if (h->ld_pad != 0) {  // (a padded buffer is not what a new handle would allocate)
     free_problem(h);
     h->ld_pad = 0;
@@ -1290,6 +1319,17 @@ int bgp_set_layout(bgp_handle* h, int64_t slab_width) {
     if (h->s_main) (void)hipStreamSynchronize(h->s_main);
     free_problem(h);
     h->slab_req = slab_width;
+  }
+  return 0;
+}
+
+int bgp_set_keep_factor(bgp_handle* h, int on) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  h->keep_factor = on != 0;
+  if (!h->keep_factor) {
+    if (h->s_main) (void)hipStreamSynchronize(h->s_main);
+    free_keep(h);
   }
   return 0;
 }
@@ -1921,7 +1961,21 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   double* Wt2 = Wt1 + ldt * NB;
   double* Ms = Wt2 + ldt * NB;  // [NB, NB] clean lower-triangular M_kk = inv(L_kk)
   double* Mt = Ms + NB * NB;    // [NB, NB] its transpose (negated in step A)
-  PhaseTimer t(h, st, BGP_T_SOLVE);
+  if (h->keep_factor && !h->keep_valid) {
+    // opt-in (bgp_set_keep_factor): a second buffer the size of the factor's, WHEN MEMORY ALLOWS - if it does not, the
+    // call proceeds without (the factor then comes back by a re-run of the fit, as without the switch)
+    if (h->A_keep_doubles != h->A_doubles) {
+      free_keep(h);
+      const std::string err_before = h->err;
+      if (dev_alloc(h, &h->dA_keep, h->A_doubles) == 0) h->A_keep_doubles = h->A_doubles;
+      else h->err = err_before;
+    }
+    if (h->dA_keep) {
+      BGP_HIP(h, hipMemcpyAsync(h->dA_keep, h->dA, (size_t)h->A_doubles * sizeof(double), hipMemcpyDeviceToDevice, st));
+      h->keep_valid = true;
+    }
+  }
+  PhaseTimer t(h, st, BGP_T_GRAD);
   h->factor_consumed = true;  // from here on the storage no longer holds a factor, whatever happens below
   // row block [K0, K0 + nbk) x columns [0, K0) of the stored triangle <-> its transpose Wt[0:K0, 0:nbk] (one launch per slab)
   auto row_block = [&](int64_t K0, int64_t nbk, double* Wt, bool out) -> int {
@@ -2011,6 +2065,9 @@ int bgp_gemm_nt_async_dev(bgp_handle* h, int mode, double* C_dev, int64_t ldc, c
   if (rc) return rc;
   if (!C_dev || !A_dev || !B_dev || mode < 0 || mode > 3) return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: bad arguments (mode=%d)", mode);
   if (btri && mode != 1) return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: btri needs mode 1");
+  if (m < 0 || n < 0 || k < 0 || ldc < m || lda < m || ldb < n)
+    return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: bad shape m=%lld n=%lld k=%lld ldc=%lld lda=%lld ldb=%lld", (long long)m, (long long)n,
+                    (long long)k, (long long)ldc, (long long)lda, (long long)ldb);
   return launch_gemm_nt(h, h->s_main, mode, mode == 1 ? 64 : 128, C_dev, ldc, A_dev, lda, B_dev, ldb, m, n, k, lower, nullptr, btri);
 }
 
@@ -2020,6 +2077,9 @@ int bgp_block_copy_dev(bgp_handle* h, const double* src_dev, int64_t lds, int64_
   if (rc) return rc;
   if (!src_dev || !dst_dev || rows < 0 || cols < 0) return bgp_fail(h, -1, "bgp_block_copy_dev: bad arguments");
   if (trans && src_dev == dst_dev) return bgp_fail(h, -1, "bgp_block_copy_dev: a transposition can not be in place");
+  if (lds < rows || ldd < (trans ? cols : rows))
+    return bgp_fail(h, -1, "bgp_block_copy_dev: leading dimension shorter than a column (rows=%lld cols=%lld lds=%lld ldd=%lld trans=%d)",
+                    (long long)rows, (long long)cols, (long long)lds, (long long)ldd, trans);
   return launch_block_copy(h, h->s_main, src_dev, lds, rows, cols, dst_dev, ldd, trans, scale, tri);
 }
 
@@ -2054,6 +2114,7 @@ int bgp_grad_reduce_block_dev(bgp_handle* h, const double* X_dev, int64_t N, int
   if (rc) return rc;
   if (!X_dev || !P_dev || !alpha_dev || !acc_dev || N < 1 || r0 < 0 || nrows < 1 || ncols < 1 || ncols > nrows)
     return bgp_fail(h, -1, "bgp_grad_reduce_block_dev: bad arguments");
+  if (ldp < nrows) return bgp_fail(h, -1, "bgp_grad_reduce_block_dev: ldp=%lld shorter than the block's %lld rows", (long long)ldp, (long long)nrows);
   FillParams p;
   if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
   if (r0 >= N) {  // a block of the padding: nothing to add

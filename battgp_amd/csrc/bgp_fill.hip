@@ -529,7 +529,9 @@ template <int KID>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const double* __restrict__ x, int64_t n, int64_t r0,
                                                           const double* __restrict__ P, int64_t ldp,
                                                           const double* __restrict__ alpha, int nti, int ntj,
-                                                          double* __restrict__ part) {
+                                                          int64_t iend, int64_t jend, double* __restrict__ part) {
+  // iend / jend: one past the last row / column of the described block that lies inside the matrix
+  // (min(n, r0 + nrows), min(n, r0 + ncols)): a block that is not a whole number of tiles is not read beyond its edge
   constexpr int DD = BGP_MAX_DIM;
   const int D = p.D;
   __shared__ double sB[FT_COLS][DD];
@@ -564,14 +566,14 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(FillParams p, const do
     __syncthreads();
     for (int c = 0; c < FT_COLS; ++c) {
       const int64_t j = j0 + c;
-      if (j >= n) break;
+      if (j >= jend) break;
       double b[DD];
 #pragma unroll
       for (int d = 0; d < DD; ++d) b[d] = sB[c][d];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int64_t ii = i + r;
-        if (ii < j || ii >= n) continue;  // strict upper triangle of the block; rows past the matrix (padding)
+        if (ii < j || ii >= iend) continue;  // strict upper triangle of the block; rows past the block / the matrix (padding)
         const double wgt = (ii == j) ? 1.0 : 2.0;
         const double W = wgt * (al[r] * sAl[c] - P[(ii - r0) + (j - r0) * ldp]);
         if (ii == j) acc[0] += W;
@@ -694,8 +696,9 @@ int launch_grad_reduce(bgp_handle* h, hipStream_t st, const FillParams& p, const
   const int64_t nb = lower_blocks(nti, ntj);
   if (nb <= 0) return 0;
   if (nb > 0x7fffffffLL) return bgp_fail(h, -1, "grad_reduce: grid too large");
+  const int64_t iend = std::min(n, r0 + nrows), jend = std::min(n, r0 + ncols);
   BGP_KID_SWITCH(p.kid, hipLaunchKernelGGL((grad_reduce_kernel<KID_>), dim3((unsigned)nb), dim3(256), 0, st, p, x, n, r0, P,
-                                           ldp, alpha, nti, ntj, part));
+                                           ldp, alpha, nti, ntj, iend, jend, part));
   BGP_HIP(h, hipGetLastError());
   hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(1024), 0, st, part, nb, out, accumulate);
   BGP_HIP(h, hipGetLastError());

@@ -92,11 +92,15 @@ struct bgp_handle {
   bool alpha_ready = false;
   bool factor_consumed = false;  // bgp_lml_grad has overwritten L with Sigma^-1 in place: the next call that needs the factor
                                  // re-runs the fit on the resident data first (ensure_factor)
+  bool keep_factor = false;      // bgp_set_keep_factor: bgp_lml_grad saves the factor storage first (when memory allows) and
+  bool keep_valid = false;       // ensure_factor copies it back instead of re-running the fit; dA_keep holds the current factor
   double jitter_used = 0.0, lml = 0.0;
   // device buffers
   double* dX = nullptr;      // [N, D] row-major
   double* dy = nullptr;      // [N]
   double* dA = nullptr;      // column slabs (SlabView) of [lda, Npad] column-major, lower triangle = Sigma then L
+  double* dA_keep = nullptr; // copy of dA taken by bgp_lml_grad under keep_factor (A_keep_doubles doubles, 0 = none)
+  int64_t A_keep_doubles = 0;
   double* dInv = nullptr;    // [Npad/64][64*64] inverses of the diagonal tiles of L
   double* dz = nullptr;      // [Npad] z = L^-1 y (zero in the padding)
   double* dalpha = nullptr;  // [Npad]

@@ -109,6 +109,11 @@ class ExactGPEngine:
         (~4 N (N + W) B, what lets N = 262 144 fit one MI355X), 0 = automatic (default)."""
         self._check(self._lib.bgp_set_layout(self._h, int(slab_width)), "bgp_set_layout")
 
+    def set_keep_factor(self, on: bool = True) -> None:
+        """Opt-in: ``lml_grad`` saves the factor into a second buffer first (when memory allows) and the next call that
+        needs it copies it back instead of re-running the fit (``bgp_set_keep_factor``)."""
+        self._check(self._lib.bgp_set_keep_factor(self._h, int(bool(on))), "bgp_set_keep_factor")
+
     def debug_set_ld_pad(self, extra_rows: int) -> None:
         """Tests / diagnostics: unused rows appended to every column of the factor buffer from the next fit on
         (``bgp_debug_set_ld_pad``): BASELINE-size element strides on a small problem."""
@@ -279,7 +284,7 @@ class ExactGPEngine:
         self._lib.bgp_phase_times(self._h, dptr(t), _lib.T_COUNT)
         names = [
             "h2d_ms", "fill_ms", "potrf_ms", "solve_ms", "cross_ms", "var_ms", "d2h_ms",
-            "trail_ms", "trail_flop", "fill_bytes", "trail_launches", "trail_union_ms",
+            "trail_ms", "trail_flop", "fill_bytes", "trail_launches", "trail_union_ms", "grad_ms", "restore_ms",
         ]
         return dict(zip(names, (float(v) for v in t)))
 

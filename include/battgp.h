@@ -54,7 +54,7 @@ enum {
   BGP_T_H2D = 0,      /* host->device upload of X, y                    */
   BGP_T_FILL = 1,     /* covariance fill  K + (noise+jitter) I           */
   BGP_T_POTRF = 2,    /* blocked Cholesky (all attempts of the ladder)   */
-  BGP_T_SOLVE = 3,    /* z gather + log det + z^T z; lazy alpha = L^-T z; or the gradient pass */
+  BGP_T_SOLVE = 3,    /* z gather + log det + z^T z; lazy alpha = L^-T z */
   BGP_T_CROSS = 4,    /* cross-covariance fill (+ mean for mean-only predictions) */
   BGP_T_VAR = 5,      /* V^T = K_*X L^-T pass (if not fused), mean = V^T z, variance */
   BGP_T_D2H = 6,      /* device->host of results                         */
@@ -63,7 +63,11 @@ enum {
   BGP_T_FILL_BYTES = 9, /* algorithmic bytes written by the last training fill */
   BGP_T_TRAIL_LAUNCHES = 10, /* number of those trailing-update launches */
   BGP_T_TRAIL_UNION = 11, /* time during which at least one of them was running (they overlap on two streams) */
-  BGP_T_COUNT = 12
+  BGP_T_GRAD = 12,    /* bgp_lml_grad: Sigma^-1 in place over the factor + the fused reduction pass */
+  BGP_T_RESTORE = 13, /* bringing the factor back after a gradient consumed it (copy under bgp_set_keep_factor, else a
+                         re-run of the fit on the resident data); 0 if the last call needed none.  The fit's own
+                         FILL / POTRF / SOLVE / TRAIL* slots are NOT touched by that re-run */
+  BGP_T_COUNT = 14
 };
 
 /* Library version (major*10000 + minor*100 + patch). */
@@ -177,6 +181,14 @@ int bgp_fit_predict_dev(bgp_handle* h, const double* X_dev, const double* y_dev,
  * hyper-parameters before every gradient anyway.  Replaces the autograd backward of src/gp/training.py:41
  * (loss.backward()) up to the factor -1/N and the raw-parameter chain rule, which stay on the host. */
 int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad);
+
+/* Opt-in: bgp_lml_grad first saves the factor storage into a second buffer of the same size (8 N^2 B in the full-square
+ * layout, ~4 N (N + W) B in slabs; one device-to-device copy, ~2 x that / HBM bandwidth), and the next call that needs the
+ * factor copies it back instead of re-running the N^3/3 fit: a prediction at the optimum after
+ * train_hyperparameters (src/batt_models/battcellgp_full.py:127-166 followed by :168-195) costs no second
+ * factorisation.  "When memory allows": if the second buffer can not be allocated the gradient proceeds without it and
+ * the factor comes back by the re-run, exactly as with the switch off (default).  on = 0 frees the buffer. */
+int bgp_set_keep_factor(bgp_handle* h, int on);
 
 /* PREDICT: posterior of the latent f at Xq[M,D] (no noise added):
  *   mean = K_*X alpha;  var = diag(K_**) - colsumsq(L^-1 K_X*), floored at min_var
@@ -342,7 +354,8 @@ int bgp_gemv_t_dev(bgp_handle* h, const double* A_dev, int64_t ld, int64_t rows,
  * starts on the diagonal: rows [r0, r0 + nrows) x columns [r0, r0 + ncols) of the matrix, element (i, j) at
  * P_dev[(i - r0) + (j - r0) ldp] (a column panel of the sharded store).  acc_dev[0 .. nacc) is increased by
  * sum' (alpha_i alpha_j - P_ij) dSigma_ij/d(.) of that block (accumulate == 0: overwritten).  X_dev [N, D] row-major,
- * alpha_dev [>= r0 + nrows].  bgp_grad_finish turns the (all-reduced) accumulators, copied to the host, into
+ * alpha_dev [>= min(N, r0 + nrows)].  1 <= ncols <= nrows <= ldp; the block need not be a whole number of the kernel's
+ * 512 x 32 tiles - nothing outside the described rows and columns is read.  bgp_grad_finish turns the (all-reduced) accumulators, copied to the host, into
  * d lml / d theta in the layout of hyp - the same arithmetic as bgp_lml_grad. */
 int bgp_grad_nacc(void);
 int bgp_grad_reduce_block_dev(bgp_handle* h, const double* X_dev, int64_t N, int D, int64_t r0, int64_t nrows, int64_t ncols,

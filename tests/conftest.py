@@ -16,6 +16,11 @@ def pytest_addoption(parser):
         help="development aid while no GPU is at hand: run (a selection of) the -m gpu tests against the CPU build of the "
              "kernel sources (tests/emu); tests that need torch CUDA tensors still need the GPU",
     )
+    parser.addoption(
+        "--emu-fault", action="append", default=[], metavar="SYMBOL",
+        help="with --emu: make this C-ABI entry point fail (return -1) - the rehearsal that a fault in a younger layer, "
+             "e.g. bgp_lml_grad, stops `-m gpu -x` only AFTER the core fit / predict / natural-size modules (GPU_ORDER)",
+    )
 
 
 def pytest_configure(config):
@@ -26,13 +31,18 @@ def pytest_configure(config):
 
         fake_cuda_tensors()
         config._emu = installed()
-        config._emu.__enter__()
+        lib = config._emu.__enter__()
+        for sym in config.getoption("--emu-fault"):
+            getattr(lib, sym)  # must exist
+            setattr(lib, sym, lambda *a, **k: -1)
 
 
 # The driver runs the GPU suite with -x: what is most basic (and longest validated on the hardware) goes first, so that a
 # failure in a younger layer (adaptor, sharded driver, optional schedules) can not cut the core parity record short.
-GPU_ORDER = ["test_gpu_parity", "test_gpu_pins_and_sizes", "test_gpu_slab_layout", "test_gpu_adaptor", "test_gpu_sharded", "test_gpu_c_caller",
-             "test_gpu_zz_optional_schedules"]
+# The LML gradient (every kernel of it younger than the last hardware contact) has its own module BEHIND the fit / predict /
+# natural-size / slab modules, so BASELINE configs 2 and 3 are reached whatever the gradient does.
+GPU_ORDER = ["test_gpu_parity", "test_gpu_pins_and_sizes", "test_gpu_slab_layout", "test_gpu_grad", "test_gpu_adaptor", "test_gpu_sharded",
+             "test_gpu_c_caller", "test_gpu_zz_optional_schedules"]
 
 
 def pytest_collection_modifyitems(config, items):

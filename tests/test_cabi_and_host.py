@@ -341,3 +341,26 @@ def test_header_is_plain_c_and_a_c_program_drives_the_abi(tmp_path):
     assert r.returncode == 0 and "c_caller ok" in r.stdout, r.stdout + r.stderr
     got = np.array([float(v) for v in r.stdout.splitlines()[0].split("grad")[1].split()])
     assert np.all(np.abs(got - grad) <= 1e-5 * np.abs(grad) + 1e-7 * np.abs(grad).max()), (got, grad)
+
+
+def test_gradient_tests_sit_behind_the_core_gpu_modules():
+    """The driver runs `pytest -m gpu -x`: nothing in the modules ordered BEFORE tests/test_gpu_grad.py may reach the
+    LML-gradient kernels (the youngest device code), or a fault there leaves BASELINE configs 2 and 3 unreached.
+    (The dynamic rehearsal of the same thing: `pytest -m gpu -x --emu --emu-fault bgp_lml_grad`)"""
+    import ast
+
+    import conftest
+
+    order = conftest.GPU_ORDER
+    assert "test_gpu_grad" in order
+    core = order[: order.index("test_gpu_grad")]
+    assert core[:3] == ["test_gpu_parity", "test_gpu_pins_and_sizes", "test_gpu_slab_layout"]
+    reaches_gradient = {"lml_grad", "bgp_lml_grad", "train_hyperparameters", "optimize", "train_exact_gp_adam", "train_exact_gp_lbfgs",
+                        "train_exact_gp_botorch", "bgp_grad_reduce_block_dev", "set_keep_factor"}
+    for mod in core:
+        tree = ast.parse(open(os.path.join(ROOT, "tests", mod + ".py")).read())
+        used = {n.attr for n in ast.walk(tree) if isinstance(n, ast.Attribute)} | {n.id for n in ast.walk(tree) if isinstance(n, ast.Name)}
+        assert not (used & reaches_gradient), (mod, used & reaches_gradient)
+    # and the gradient module does hold them
+    src = open(os.path.join(ROOT, "tests", "test_gpu_grad.py")).read()
+    assert src.count("lml_grad()") >= 8

@@ -92,19 +92,13 @@ def test_slab_layout_saves_the_upper_triangle():
     assert slabbed["lml"] == full["lml"] and np.array_equal(slabbed["m"], full["m"])
 
 
-def test_slab_layout_gradient_and_refit_and_cov():
-    from oracle.exact_gp import lml_and_grad
-
+def test_slab_layout_refit_and_cov():
     n = 1500
     x, y = synthetic.make_cell_data(n, seed=11)
     xq = synthetic.make_query(x, 40)
     e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
     e.set_layout(512)
     e.fit(x, y)
-    g = e.lml_grad()
-    lml_ref, g_ref = lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)
-    assert abs(e.lml - lml_ref) <= REL * abs(lml_ref)
-    assert np.allclose(g, g_ref, rtol=1e-5), (g, g_ref)
     hyp2 = synthetic.HYP_BATTGP * np.array([2.0, 0.5, 1.5, 0.7, 1.2, 0.9])
     lml2 = e.refit(hyp2)
     assert e.layout()[0] == 512
