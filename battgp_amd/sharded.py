@@ -209,13 +209,23 @@ class DeviceBackend:
         with self.on_stream():
             dist.all_reduce(t) if op is None else dist.all_reduce(t, op=op)
 
-    def reduce(self, dist, t, dst):
+    def reduce_start(self, dist, t, dst):
         with self.on_stream():
-            dist.reduce(t, dst=dst)
+            return dist.reduce(t, dst=dst, async_op=True)
 
-    def allreduce_start(self, dist, t):
+    def allgather_start(self, dist, recv, send):
+        """recv [world * len(send)] <- every rank's send, in rank order"""
         with self.on_stream():
-            return dist.all_reduce(t, async_op=True)
+            return dist.all_gather_into_tensor(recv, send, async_op=True)
+
+    def unshuffle(self, recv, wt, world, nslots, nb, ncols):
+        """The gathered chunks - rank r's [nslots * nb, ncols] column-major block holds its panels' pieces in slot order -
+        into the natural row order of wt [world * nslots * nb, ncols]: rows of slot i of rank r go to panel i * world + r.
+        One strided device copy (a buffer operation like the broadcast buffers' slicing; no arithmetic)."""
+        with self.on_stream():
+            cnt = world * nslots * nb * ncols
+            src = recv[:cnt].view(world, ncols, nslots, nb).permute(1, 2, 0, 3)
+            wt[:cnt].view(ncols, nslots, world, nb).copy_(src)
 
     # ---- gradient: Sigma^-1 in place over the distributed factor ------------------------------------------
     def gemm(self, mode, c, coff, ldc, a, aoff, lda, b, boff, ldb, m, n, k, lower=0, btri=0):
@@ -301,10 +311,6 @@ class DeviceBackend:
         with self.on_stream():
             vec[c0 : c0 + seg.shape[0]] = seg
 
-    def fill_zero(self, buf, count):
-        with self.on_stream():
-            buf[: int(count)].zero_()
-
     def scalar(self, value):
         with self.on_stream():
             return self.torch.full((1,), float(value), dtype=self.torch.float64, device=self.device)
@@ -322,13 +328,54 @@ class ShardedExactGP:
         self._times = {}
         self._shape = None
         self._factor_consumed = False  # lml_grad() has turned the stored factor into Sigma^-1
+        self._comm = {}                # phase -> kind -> [calls, payload bytes, bytes received by THIS rank]
+        self._phase = "other"
 
     def set_hyp(self, hyp) -> None:
-        """New hyper-parameters for the next :meth:`fit` (every rank must pass the same vector)."""
+        """New hyper-parameters for the next :meth:`fit` (every rank must pass the same vector).  The model is unfitted
+        from here on: :meth:`predict` / :meth:`lml_grad` raise until :meth:`fit` has run with them (the single-GPU
+        engine does the same in ``bgp_set_kernel``)."""
         self.hyp = np.asarray(hyp, dtype=np.float64).copy()
         eng = getattr(self, "engine", None)
         if eng is not None:
             eng.set_hyp(self.hyp)
+        self.lml = None
+        self._factor_consumed = False
+
+    # ---- bookkeeping of the exchange (host side; the only scaling evidence obtainable without a multi-GPU node) ----
+    def _count(self, kind: str, nbytes: int, root: int | None = None) -> None:
+        """One collective of `nbytes` payload.  Bytes RECEIVED by this rank under the ring / chain algorithms RCCL uses on
+        point-to-point xGMI links: broadcast - the payload on every rank but the root; all-gather of equal chunks -
+        (w-1) chunks; all-reduce - 2 (w-1)/w of the payload; reduce - (w-1)/w of it (average over the chain)."""
+        w = self.world
+        if kind == "broadcast":
+            recv = 0 if root == self.rank else nbytes
+        elif kind == "all_gather":
+            recv = (w - 1) * nbytes  # nbytes = one rank's chunk
+        elif kind == "all_reduce":
+            recv = 2 * nbytes * (w - 1) // w
+        elif kind == "reduce":
+            recv = nbytes * (w - 1) // w
+        else:
+            raise ValueError(kind)
+        c = self._comm.setdefault(self._phase, {}).setdefault(kind, [0, 0, 0])
+        c[0] += 1
+        c[1] += int(nbytes)
+        c[2] += int(recv)
+
+    def comm_bytes(self, reset: bool = False) -> dict:
+        """``{phase: {kind: (calls, payload_bytes, received_bytes)}}`` since the last reset; phases: ``fit`` (fill,
+        factorisation, z / log det), ``predict``, ``grad_a`` (M = L^-1), ``grad_alpha``, ``grad_b`` (P = M^T M),
+        ``grad_reduce``."""
+        out = {ph: {k: tuple(v) for k, v in kinds.items()} for ph, kinds in self._comm.items()}
+        if reset:
+            self._comm = {}
+        return out
+
+    def _allreduce(self, t, op=None):
+        if self.dist is not None:
+            self._count("all_reduce", 8 * int(t.shape[0]))
+            self.be.allreduce(self.dist, t, op=op)
 
     def timers(self) -> dict:
         """host wall-clock of the last fit / predict on this rank (seconds)"""
@@ -352,8 +399,14 @@ class ShardedExactGP:
         self.poff, total = lay.offsets(self.rank)
         self.store = be.empty(max(1, total))
         self.inv = {j: be.empty((lay.width(j) // 64) * 4096) for j in mine}
-        # packed panel + failing-minor flag slot; two of them: the broadcast of panel k+1 is in flight while panel k is read
-        self.pbufs = [be.empty(lay.nb * lay.nrows + 1), be.empty(lay.nb * lay.nrows + 1)]
+        # packed panel + failing-minor flag slot; two of them: the broadcast of panel k+1 is in flight while panel k is read.
+        # The gradient's step (B) reuses them as the gathered / the assembled transposed row block, whose leading dimension
+        # is a whole number of rounds of `world` panels: up to (world - 1) nb rows more than the matrix has
+        nslots = -(-lay.npanels // self.world)
+        per_buf = max(lay.nb * lay.nrows + 1, self.world * nslots * lay.nb * lay.nb)
+        self.pbufs = [be.empty(per_buf), be.empty(per_buf)]
+        self.sbuf = be.empty(nslots * lay.nb * lay.nb) if self.world > 1 else None  # this rank's pieces of one row block
+        self.wk = [be.empty(lay.nb * lay.nb) for _ in range(4)]  # nb x nb work blocks of the gradient
         self._shape = (n, d)
         return lay
 
@@ -366,6 +419,7 @@ class ShardedExactGP:
         self._allocate(n, d)
         self.n, self.d = n, d
         self.x_dev, self.y_dev = be.upload(x), be.upload(y)
+        self._phase = "fit"
         self._fit_resident()
         self._times["fit_s"] = time.perf_counter() - t_start
         return self.lml
@@ -399,9 +453,8 @@ class ShardedExactGP:
             be.set_segment(z, c0, be.aug_row(self.store, self.poff[j], lay.ld(j), lay.rows_from(j), w))
             logdet += be.diag_logsum(self.store, self.poff[j], lay.ld(j), w)
         ld_t = be.scalar(logdet)
-        if self.dist is not None:
-            be.allreduce(self.dist, z)
-            be.allreduce(self.dist, ld_t)
+        self._allreduce(z)
+        self._allreduce(ld_t)
         self.z = z
         zz = be.sumsq(z, lay.npad)
         self.lml = -0.5 * zz - float(be.to_host(ld_t)[0]) - 0.5 * n * math.log(2.0 * math.pi)
@@ -413,7 +466,7 @@ class ShardedExactGP:
         if self.dist is None:
             return flag
         t = self.be.scalar(flag)
-        self.be.allreduce(self.dist, t, op=self.dist.ReduceOp.MAX)
+        self._allreduce(t, op=self.dist.ReduceOp.MAX)
         return int(self.be.to_host(t)[0])
 
     def _enqueue_factorisation(self) -> None:
@@ -432,7 +485,9 @@ class ShardedExactGP:
         def start_bcast(k, buf):
             if self.dist is None:
                 return None
-            return be.bcast_start(self.dist, buf[: lay.width(k) * lay.rows_from(k) + 1], lay.owner(k))
+            cnt = lay.width(k) * lay.rows_from(k) + 1
+            self._count("broadcast", 8 * cnt, lay.owner(k))
+            return be.bcast_start(self.dist, buf[:cnt], lay.owner(k))
 
         if self.rank == lay.owner(0):
             factor_and_pack(0, pbufs[0])
@@ -461,11 +516,19 @@ class ShardedExactGP:
 
     # ---- predict ----------------------------------------------------------------------------------
     def predict(self, xq: np.ndarray, min_var: float = 1e-10):
-        """(mean, var) of the latent f at xq, identical on every rank."""
+        """(mean, var) of the latent f at xq, identical on every rank.
+
+        Right-looking over the panels with a ONE-STEP LOOK-AHEAD on the exchange, like the factorisation: at step k the
+        owner solves ``E_k``, applies it to the columns of panel k+1 FIRST, the reduce of block k+1 to its owner starts
+        (asynchronously, on the communicator's stream), and the owner's update of all later columns runs underneath it."""
+        if self.lml is None:
+            raise RuntimeError("predict: fit first (set_hyp() leaves the model unfitted)")
         t_start = time.perf_counter()
         lay, be = self.lay, self.be
         if self._factor_consumed:  # same data, same hyper-parameters, same ladder: the factor comes back as it was
+            self._phase = "fit"
             self._fit_resident()
+        self._phase = "predict"
         xq = np.ascontiguousarray(xq, dtype=np.float64)
         m = xq.shape[0]
         mpad = round_up(m, 16)
@@ -478,29 +541,42 @@ class ShardedExactGP:
             be.cross_fill(xq_dev, m, mpad, self.x_dev, self.n, self.d, lay.npad, w, lde)
         mean_p, var_p, tmp = be.zeros(mpad), be.zeros(mpad), be.zeros(mpad)
         ek = be.empty(mpad * lay.nb)
+
+        def start_reduce(k):
+            if self.dist is None:
+                return None
+            c0, nbk = lay.col0(k), lay.width(k)
+            self._count("reduce", 8 * nbk * lde, lay.owner(k))
+            return be.reduce_start(self.dist, w[c0 * lde : (c0 + nbk) * lde], lay.owner(k))
+
+        work = start_reduce(0)
         for k in range(lay.npanels):
             owner, c0, nbk = lay.owner(k), lay.col0(k), lay.width(k)
-            blk = w[c0 * lde : (c0 + nbk) * lde]
-            if self.dist is not None:
-                be.reduce(self.dist, blk, owner)
-            if self.rank == owner:
-                be.copy_into(ek[: nbk * lde], blk)
+            mine = self.rank == owner
+            if work is not None:
+                be.bcast_wait(work)
+            nxt = lay.width(k + 1) if k + 1 < lay.npanels else 0
+            if mine:
+                be.copy_into(ek[: nbk * lde], w[c0 * lde : (c0 + nbk) * lde])
                 be.solve_panel(ek, 0, lde, mpad, self.store, self.poff[k], lay.ld(k), nbk, self.inv[k])
-                rest = lay.npad - (c0 + nbk)
+                if nxt:  # what block k+1 still misses from this rank
+                    be.update_rows(w, (c0 + nbk) * lde, lde, mpad, ek, lde, self.store, self.poff[k] + nbk, lay.ld(k), nxt, nbk)
+            if nxt:
+                work = start_reduce(k + 1)
+            if mine:
+                rest = lay.npad - (c0 + nbk + nxt)
                 if rest > 0:
-                    be.update_rows(w, (c0 + nbk) * lde, lde, mpad, ek, lde, self.store, self.poff[k] + nbk, lay.ld(k), rest, nbk)
+                    be.update_rows(w, (c0 + nbk + nxt) * lde, lde, mpad, ek, lde, self.store, self.poff[k] + nbk + nxt, lay.ld(k), rest, nbk)
                 be.rowdot(ek, lde, mpad, nbk, self.z, c0, tmp)
                 be.add_into(mean_p, tmp)
                 be.rowdot(ek, lde, mpad, nbk, None, 0, tmp)
                 be.add_into(var_p, tmp)
-        if self.dist is not None:
-            be.allreduce(self.dist, mean_p)
-            be.allreduce(self.dist, var_p)
+        self._allreduce(mean_p)
+        self._allreduce(var_p)
         mean = be.to_host(mean_p)[:m]
         var = be.to_host(be.var_finish(xq_dev, m, self.d, var_p, min_var))[:m]
         self._times["predict_s"] = time.perf_counter() - t_start
         return mean, var
-
 
     # ---- gradient ---------------------------------------------------------------------------------
     def lml_grad(self) -> np.ndarray:
@@ -514,27 +590,31 @@ class ShardedExactGP:
             ONE rank-``nb`` update ``X[K1:, j] -= L[K1:, k] X_kj`` per panel on the MFMA kernel; the owner writes its own
             panel ``[M_kk ; -L[K1:, k] M_kk]``.  The pack and broadcast of panel k+1 run ahead of the updates of step k.
         (B) ``P = M^T M``, row blocks from the top.  Step k: row block k of ``M`` (spread over the owners of the panels
-            ``j <= k``) is gathered, transposed, into ``Wt[K1, nb]`` on every rank (an all-reduce of the zero-padded
-            pieces, issued one step ahead); every rank adds the rank-``nb`` SYRK ``P[J0:K0, j] += Wt[J0:K0] Wt[j]^T`` to
-            its panels ``j < k``, transforms their row block k (``M_kj <- M_kk^T M_kj``), the owner forms ``P_kk``.
+            ``j <= k``) is assembled, transposed, into ``Wt[K1, nb]`` on every rank by ONE ALL-GATHER, issued one step
+            ahead: each rank packs the pieces of ITS panels slot by slot (panel j -> slot j // world), the gathered
+            chunks are put into the natural row order by one strided copy (panel = slot * world + rank); every rank adds
+            the rank-``nb`` SYRK ``P[J0:K0, j] += Wt[J0:K0] Wt[j]^T`` to its panels ``j < k``, transforms their row
+            block k (``M_kj <- M_kk^T M_kj``), the owner forms ``P_kk``.
 
         ``alpha = M^T z`` is local per panel between (A) and (B); the reduction over each local panel's lower trapezoid
         re-evaluates the kernel derivatives, and ONE all-reduce of the few accumulators ends it.  Per rank: ``2/3 N^3 /
-        world`` flop, ~``4 N^2`` bytes received in each of (A) and (B), no second ``N^2`` buffer (the packed-panel
-        buffers of the factorisation are reused).  The factor is consumed: the next :meth:`predict` re-runs the
-        factorisation on the resident inputs."""
+        world`` flop, ~``4 N^2 (w-1)/w`` bytes received in each of (A) and (B) (:meth:`comm_bytes` counts them), no second
+        ``N^2`` buffer (the packed-panel buffers of the factorisation are reused).  The factor is consumed: the next
+        :meth:`predict` re-runs the factorisation on the resident inputs."""
         if self.lml is None:
-            raise RuntimeError("lml_grad: fit first")
+            raise RuntimeError("lml_grad: fit first (set_hyp() leaves the model unfitted)")
         if self._factor_consumed:
+            self._phase = "fit"
             self._fit_resident()
         t_start = time.perf_counter()
         lay, be, dist = self.lay, self.be, self.dist
+        world = self.world
         mine = lay.local_panels(self.rank)
         nb, npad = lay.nb, lay.npad
-        mk, mt = be.empty(nb * nb), be.empty(nb * nb)
-        t1, t3 = be.empty(nb * nb), be.empty(nb * nb)
+        mk, mt, t1, t3 = self.wk
         pbufs = self.pbufs
         self._factor_consumed = True
+        self._phase = "grad_a"
 
         def geom(k):
             c0, nbk = lay.col0(k), lay.width(k)
@@ -553,6 +633,7 @@ class ShardedExactGP:
             if dist is None:
                 return None
             _, nbk, _, R = geom(k)
+            self._count("broadcast", 8 * R * nbk, lay.owner(k))
             return be.bcast_start(dist, buf[: R * nbk], lay.owner(k))
 
         if self.rank == lay.owner(0):
@@ -585,50 +666,66 @@ class ShardedExactGP:
                 be.block_copy(cur, 0, R, nbk, nbk, self.store, off, ld)
 
         # ---- alpha = M^T z: each panel's columns against the rows it stores -----------------------------------
+        self._phase = "grad_alpha"
         alpha = be.zeros(npad)
         for j in mine:
             J0, nbj = lay.col0(j), lay.width(j)
             be.gemv_t(self.store, self.poff[j], lay.ld(j), npad - J0, nbj, self.z, J0, alpha, J0)
-        if dist is not None:
-            be.allreduce(dist, alpha)
+        self._allreduce(alpha)
 
         # ---- (B) P = M^T M -----------------------------------------------------------------------------
-        def gather(k, buf):
-            """my pieces of (row block k of M)^T into buf [K1, nbk]; the sum over the ranks is the whole block"""
+        # Wt = pbufs[0]: (row block k of M)^T in natural row order, leading dimension ldw(k) = a whole number of rounds of
+        # `world` panels (>= K1); pbufs[1]: the gathered chunks; sbuf: this rank's chunk.  All three single-buffered: the
+        # gather of block k+1 is issued behind the copy that empties pbufs[1], and Wt is rewritten only at the next step.
+        # (One rank: the chunk IS the block - packed straight into Wt, which then alternates between the two buffers,
+        # block k+1 being packed while step k still reads block k.)
+        self._phase = "grad_b"
+        gathered = pbufs[1]
+
+        def slots(k):
+            return -(-(k + 1) // world)  # panels 0..k dealt round-robin: slots per rank
+
+        def gather(k):
+            """my pieces of (row block k of M)^T, slot by slot; then the all-gather of every rank's chunk"""
             K0, nbk, K1, _ = geom(k)
-            if dist is not None:
-                be.fill_zero(buf, K1 * nbk)
+            rows = slots(k) * nb  # rows of a chunk
+            dst = self.sbuf if dist is not None else pbufs[k % 2]
             for j in (p for p in mine if p < k):
                 J0, nbj = lay.col0(j), lay.width(j)
-                be.block_copy(self.store, self.poff[j] + (K0 - J0), lay.ld(j), nbk, nbj, buf, J0, K1, trans=1)
+                be.block_copy(self.store, self.poff[j] + (K0 - J0), lay.ld(j), nbk, nbj, dst, (j // world) * nb, rows, trans=1)
             if k in mine:
-                be.block_copy(self.store, self.poff[k], lay.ld(k), nbk, nbk, buf, K0, K1, trans=1, tri=1)  # M_kk^T
-            return be.allreduce_start(dist, buf[: K1 * nbk]) if dist is not None else None
+                be.block_copy(self.store, self.poff[k], lay.ld(k), nbk, nbk, dst, (k // world) * nb, rows, trans=1, tri=1)  # M_kk^T
+            if dist is None:
+                return None
+            self._count("all_gather", 8 * rows * nbk)
+            return be.allgather_start(dist, gathered[: world * rows * nbk], self.sbuf[: rows * nbk])
 
-        work = gather(0, pbufs[0])
+        work = gather(0)
         for k in range(lay.npanels):
-            cur, nxt = pbufs[k % 2], pbufs[(k + 1) % 2]
             K0, nbk, K1, _ = geom(k)
+            ldw = world * slots(k) * nb
+            wt = pbufs[0] if dist is not None else pbufs[k % 2]
             if work is not None:
                 be.bcast_wait(work)
+                be.unshuffle(gathered, wt, world, slots(k), nb, nbk)
             if k + 1 < lay.npanels:  # row block k+1 is untouched by step k: its exchange runs under this step's updates
-                work = gather(k + 1, nxt)
+                work = gather(k + 1)
             for j in (p for p in mine if p < k):
                 J0, nbj = lay.col0(j), lay.width(j)
                 off, ld = self.poff[j], lay.ld(j)
-                be.gemm(3, self.store, off, ld, cur, J0, K1, cur, J0, K1, K0 - J0, nbj, nbk, lower=1)
-                be.gemm(1, t3, 0, nb, cur, J0, K1, cur, K0, K1, nbj, nbk, nbk)  # t3 = M_kj^T M_kk
+                be.gemm(3, self.store, off, ld, wt, J0, ldw, wt, J0, ldw, K0 - J0, nbj, nbk, lower=1)
+                be.gemm(1, t3, 0, nb, wt, J0, ldw, wt, K0, ldw, nbj, nbk, nbk)  # t3 = M_kj^T M_kk
                 be.block_copy(t3, 0, nb, nbj, nbk, self.store, off + (K0 - J0), ld, trans=1)
             if k in mine:
-                be.gemm(1, self.store, self.poff[k], lay.ld(k), cur, K0, K1, cur, K0, K1, nbk, nbk, nbk)  # P_kk = M_kk^T M_kk
+                be.gemm(1, self.store, self.poff[k], lay.ld(k), wt, K0, ldw, wt, K0, ldw, nbk, nbk, nbk)  # P_kk = M_kk^T M_kk
 
         # ---- reduction over the local panels, one all-reduce of the accumulators ----------------------------
+        self._phase = "grad_reduce"
         acc = be.grad_acc()
         for j in mine:
             J0, nbj = lay.col0(j), lay.width(j)
             be.grad_reduce(self.x_dev, self.n, self.d, J0, npad - J0, nbj, self.store, self.poff[j], lay.ld(j), alpha, acc)
-        if dist is not None:
-            be.allreduce(dist, acc)
+        self._allreduce(acc)
         grad = be.grad_finish(acc, self.d)
         self._times["grad_s"] = time.perf_counter() - t_start
         return grad

@@ -165,9 +165,18 @@ def cpu_baseline(kernel_name: str, n_cpu: int, m: int, n_second: int = 0, budget
             if chol is None:
                 raise RuntimeError("no LAPACK available for a sample of this size (torch missing or its factorisation failed)")
         t2 = time.perf_counter()
-        z = sla.solve_triangular(chol, y, lower=True, check_finite=False)
         kxs = K.kernel_matrix(kid, hyp, x, xq)
-        v = sla.solve_triangular(chol, kxs, lower=True, check_finite=False)
+        if big:
+            # the same OpenBLAS also dies in level-3 products from N = 32 768 on (dtrsm here): the solves of a big sample
+            # go through torch's LAPACK like its factorisation
+            lt = torch.from_numpy(chol)
+            rhs = torch.from_numpy(np.ascontiguousarray(np.column_stack([y, kxs])))
+            sol = torch.linalg.solve_triangular(lt, rhs, upper=False).numpy()
+            z, v = sol[:, 0].copy(), sol[:, 1:]
+            del lt, rhs
+        else:
+            z = sla.solve_triangular(chol, y, lower=True, check_finite=False)
+            v = sla.solve_triangular(chol, kxs, lower=True, check_finite=False)
         mean = v.T @ z
         var = K.kernel_diag(kid, hyp, xq) - np.einsum("ij,ij->j", v, v)
         lml = -0.5 * float(z @ z) - float(np.sum(np.log(np.diag(chol)))) - 0.5 * n * np.log(2 * np.pi)
@@ -669,7 +678,8 @@ def run_sharded(args, rank, world, local_rank, n):
     from battgp_amd.sharded import make_sharded_gp
 
     kid, hyp, desc = kernel_setup(args.kernel)
-    fault = os.environ.get("BGP_BENCH_SHARDED_FAULT", "")  # test hook (tests/test_bench_host.py): "raise:<rank>"
+    fault = os.environ.get("BGP_BENCH_SHARDED_FAULT", "")  # test hook (tests/test_bench_host.py): "raise:<rank>" before the first
+    # collective, "late:<rank>" after the last one (a failure the other ranks can not see)
     if fault == f"raise:{rank}":
         raise RuntimeError("injected fault in the sharded sub-run")
     gp = make_sharded_gp(kid, hyp, nb=args.sharded_nb, backend_name=args.backend, local_rank=local_rank)
@@ -711,6 +721,10 @@ def run_sharded(args, rank, world, local_rank, n):
         if grad_s is not None:
             rec["lml_grad"] = {"seconds": grad_s, "tflops_per_gpu": (2.0 * n**3 / 3.0) / grad_s / 1e12 / world,
                                "over_one_fit_predict": grad_s / dt, "grad": [float(v) for v in grad]}
+        # what rank 0 exchanged over all the calls above: {phase: {collective: [calls, payload B, received B]}}
+        rec["comm_bytes_rank0"] = {ph: {k: list(v) for k, v in kinds.items()} for ph, kinds in gp.comm_bytes().items()}
+    if fault == f"late:{rank}":
+        raise RuntimeError("injected late fault in the sharded sub-run")
     gp.close()
     return rec
 
@@ -811,7 +825,19 @@ def main() -> None:
                 out["cpu_baseline"] = None
             emit(out)
     if dist is not None:
-        if hung or (isinstance(sh, dict) and "error" in sh):
+        failed = hung or (isinstance(sh, dict) and "error" in sh)
+        if not hung:
+            # The way out is decided by ALL ranks together: a failure seen on one rank only (an exception after the
+            # collectives had completed) must not let that rank leave while the others wait in the barrier.  One MAX
+            # all-reduce of "something went wrong here", itself under a time limit - a rank that hung never joins it.
+            def agree():
+                t = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return {"failed": bool(t.item() > 0.0)}
+
+            verdict, hung_now = _guarded(agree, 60.0, local_rank)
+            failed = failed or hung_now or bool(verdict.get("failed")) or "error" in verdict
+        if failed:
             # a rank of the group is stuck or gone: the tear-down collectives would wait for it - the line is out, leave
             sys.stdout.flush()
             os._exit(0)

@@ -28,7 +28,7 @@ count = [0]
 @given(problems(n_max=n_max, m_max=80))
 def campaign(prob):
     count[0] += 1
-    check_problem(*prob)
+    check_problem(*prob, grad=True)
 
 
 with installed(sanitize="asan" if os.environ.get("FUZZ_ASAN") else False):

@@ -66,4 +66,4 @@ def test_slim_chain_kernels_and_split_panels_are_bit_identical(kid, n, nb):
 def test_random_problems_match_the_oracle_under_the_optional_schedules(prob):
     """the property of tests/test_gpu_parity.py::test_random_problems_match_the_oracle with the look-ahead words drawn
     from the optional schedules"""
-    check_problem(*prob)
+    check_problem(*prob, grad=True)

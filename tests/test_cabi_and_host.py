@@ -361,6 +361,8 @@ def test_gradient_tests_sit_behind_the_core_gpu_modules():
         tree = ast.parse(open(os.path.join(ROOT, "tests", mod + ".py")).read())
         used = {n.attr for n in ast.walk(tree) if isinstance(n, ast.Attribute)} | {n.id for n in ast.walk(tree) if isinstance(n, ast.Name)}
         assert not (used & reaches_gradient), (mod, used & reaches_gradient)
+        # (tests/problem_gen.py::check_problem evaluates the gradient only on request)
+        assert not any(isinstance(n, ast.keyword) and n.arg == "grad" for n in ast.walk(tree)), mod
     # and the gradient module does hold them
     src = open(os.path.join(ROOT, "tests", "test_gpu_grad.py")).read()
     assert src.count("lml_grad()") >= 8

@@ -32,7 +32,7 @@ from problem_gen import check_problem, problems  # noqa: E402
 @settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(problems())
 def test_random_problems_match_the_oracle_on_the_cpu_build(emu, prob):
-    check_problem(*prob)
+    check_problem(*prob, grad=True)
 
 
 def test_random_sharded_problems_match_the_oracle_on_the_cpu_build():

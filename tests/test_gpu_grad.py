@@ -8,8 +8,14 @@ tests/test_emu_kernels.py::test_gradient_fault_cannot_cut_the_core_record_short 
 
 import os
 
+import sys
+
 import numpy as np
 import pytest
+from hypothesis import HealthCheck, given, settings
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from problem_gen import LA_MEASURED, check_problem, problems  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -76,6 +82,14 @@ def test_lml_gradient_production_hyperparameters():
     e.close()
     # entries span 20 orders of magnitude (d/ds_w ~ 1e13): compare each relative to itself
     assert np.allclose(g, g_ref, rtol=1e-5), (g, g_ref)
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(problems(n_max=3000, m_max=400, noise_lo=-3.0, la_words=LA_MEASURED))
+def test_random_problems_gradient_matches_the_oracle(prob):
+    """the property of test_gpu_parity.py::test_random_problems_match_the_oracle (same derandomised problems: ragged N,
+    D = 1..6, all kernels, duplicated points, both panel schemes, slab layout) with the analytic gradient added"""
+    check_problem(*prob, grad=True)
+
 
 # ---------------------------------------------------------------------------------------------
 # against third-party pins (scikit-learn, torch autograd)

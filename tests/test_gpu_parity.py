@@ -460,8 +460,9 @@ def test_panel_schemes_agree_and_match_oracle(kid, n, nb):
 def test_random_problems_match_the_oracle(prob):
     """the property of tests/test_emu_property.py at sizes with dozens of panels: ragged N / M, D = 1..6, all kernels,
     random hyper-parameters, duplicated points, both panel schemes, the look-ahead words that have run on the GPU, slab
-    layout - LML, posterior and gradient against the oracle (the optional schedules built while the GPU pool was closed
-    take the same property in tests/test_gpu_zz_optional_schedules.py, in a child process)"""
+    layout - LML and posterior against the oracle; the gradient of the same problems in tests/test_gpu_grad.py (the
+    optional schedules built while the GPU pool was closed take the property in tests/test_gpu_zz_optional_schedules.py,
+    in a child process)"""
     check_problem(*prob)
 
 

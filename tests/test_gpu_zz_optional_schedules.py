@@ -12,17 +12,15 @@ import sys
 
 import pytest
 
-# Off-by-default code that has not met the hardware yet must not be able to turn the driver's `-m gpu -x` record red
-# (or eat its time limit): a failure here is reported as XFAIL, a pass as XPASS, until the first hardware measurement
-# has decided which of these variants stay (the ones that lose their A/B are deleted with this file).
-# And they do not run at all unless asked for (BGP_TEST_OPTIONAL=1; `pytest --emu` asks by itself): a kernel that hangs the
-# GPU cannot be recovered by killing the child, and the driver's round-end sequence runs smoke() and bench.py on the same
-# box right after this suite - an experiment must not be able to cost the headline record.  tools/gpu_session.sh runs
-# them in its own last stage ("optional"), after everything else of the session has been written out.
+# Off-by-default code that has not met the hardware yet does not run unless asked for (BGP_TEST_OPTIONAL=1; `pytest --emu`
+# asks by itself): a kernel that hangs the GPU cannot be recovered by killing the child, and the driver's round-end
+# sequence runs smoke() and bench.py on the same box right after this suite - an experiment must not be able to cost the
+# headline record.  tools/gpu_session.sh runs them in its own last stage ("optional"), after everything else of the
+# session has been written out.  When they DO run, a failure is a failure (no xfail): the stage goes red, and
+# tools/decide_ab.py reads its log and refuses to promote a variant whose parity case did not pass.
 _ASKED = os.environ.get("BGP_TEST_OPTIONAL") == "1" or "--emu" in sys.argv
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not _ASKED, reason="optional, off-by-default schedules: run with BGP_TEST_OPTIONAL=1 (tools/gpu_session.sh stage 'optional')"),
-              pytest.mark.xfail(strict=False, reason="optional, off-by-default schedules: never run on hardware")]
+              pytest.mark.skipif(not _ASKED, reason="optional, off-by-default schedules: run with BGP_TEST_OPTIONAL=1 (tools/gpu_session.sh stage 'optional')")]
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = os.path.join(HERE, "optional_schedule_cases.py")

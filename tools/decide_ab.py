@@ -71,8 +71,37 @@ def fill_table(folder):
     return out
 
 
+def parity_gates(folder):
+    """{"schedules": True / False / None, "fill": ...} from pytest_optional.log of the session's "optional" stage
+    (tests/test_gpu_zz_optional_schedules.py, BGP_TEST_OPTIONAL=1): True = its parity cases passed, False = one failed or
+    timed out, None = the log is missing / the cases did not run.  Only True lets a variant be promoted."""
+    gates = {"schedules": None, "fill": None}
+    path = os.path.join(folder, "pytest_optional.log")
+    if not os.path.exists(path):
+        return gates
+    text = open(path).read()
+    m = re.search(r"(\d+) passed", text)
+    failed = re.findall(r"^(?:FAILED|ERROR) \S*::(\S+)", text, flags=re.M)
+    ran = bool(m) or bool(failed)
+    if not ran or " skipped" in text and not m and not failed:
+        return gates
+    sched_bad = any("test_optional_schedules_in_a_child_process" in f for f in failed)
+    fill_bad = any("test_optional_interior_paths_of_the_fill" in f for f in failed)
+    npass = int(m.group(1)) if m else 0
+    # 2 schedule cases + 1 fill case: all three must have been seen (passed or failed) for a gate to be known
+    if npass + len(failed) >= 3:
+        gates["schedules"] = not sched_bad
+        gates["fill"] = not fill_bad
+    else:
+        gates["schedules"] = False if sched_bad else None
+        gates["fill"] = False if fill_bad else None
+    return gates
+
+
 def main(folder):
     promote, delete, undecided = [], [], []
+    gates = parity_gates(folder)
+    print(f"== parity gates from pytest_optional.log: {gates}  (True is needed for a promotion)")
     ms, identical = schedule_table(folder)
     base = ms.get(1, {})
     print(f"== Cholesky schedules (fit+predict ms; base = lookahead word 1), folder {folder}")
@@ -95,6 +124,9 @@ def main(folder):
         bad_bits = any(identical.get((la, n)) is False for n in ms[la])
         if bad_bits:
             delete.append(f"lookahead {la} ({name}): differing bits")
+        elif wins and gates["schedules"] is not True:
+            undecided.append(f"lookahead {la} ({name}) is faster at N in {wins} but its parity cases "
+                             f"{'FAILED' if gates['schedules'] is False else 'did not run'}: NOT promoted")
         elif wins:
             promote.append(f"lookahead {la} ({name}) at N in {wins}")
         elif cells:
@@ -112,8 +144,11 @@ def main(folder):
         gains = [v / base_f[k] for k, v in rates.items() if k in base_f]
         if not gains:
             undecided.append(f"fill variant {tag}: no default measurement beside it")
+        elif max(gains) > GAIN and gates["fill"] is not True:
+            undecided.append(f"fill variant {tag} is faster (best {max(gains):.3f}x) but its elementwise-bound test "
+                             f"{'FAILED' if gates['fill'] is False else 'did not run'}: NOT promoted")
         elif max(gains) > GAIN:
-            promote.append(f"fill variant {tag} (best {max(gains):.3f}x; needs its elementwise-bound test green)")
+            promote.append(f"fill variant {tag} (best {max(gains):.3f}x; elementwise-bound test green)")
         else:
             delete.append(f"fill variant {tag}: best {max(gains):.3f}x")
     print("== decision (DESIGN.md section 8: > 2 % faster AND inside its parity gate -> default there; otherwise deleted with its knob)")

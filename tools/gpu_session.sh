@@ -76,8 +76,8 @@ if has sharded; then
   timeout 900 python bench.py --mode sharded --n 131072 --kernel battgp --steps 1 --warmup 0 --cpu-n 0 --no-extras > $OUT/sharded_n131072.json 2>> $OUT/sharded.err
 fi
 if has optional; then
-  stamp "optional schedules / fill variants through the test suite (child processes, xfail(strict=False))"
-  BGP_TEST_OPTIONAL=1 timeout 1500 python -m pytest tests/test_gpu_zz_optional_schedules.py -m gpu -q -rxX > $OUT/pytest_optional.log 2>&1
+  stamp "optional schedules / fill variants through the test suite (child processes; a failure is a failure)"
+  BGP_TEST_OPTIONAL=1 timeout 1500 python -m pytest tests/test_gpu_zz_optional_schedules.py -m gpu -q -rfE > $OUT/pytest_optional.log 2>&1
   stamp "optional rc=$? $(tail -1 $OUT/pytest_optional.log)"
 fi
 python tools/decide_ab.py $OUT > $OUT/ab_decision.txt 2>&1   # the promote / delete list of DESIGN.md section 8, from the files above
