@@ -1,0 +1,104 @@
+"""Static first-contact gate for the kernels (CPU suite; hipcc cross-compiles gfx950 without a GPU).
+
+The CPU build of the kernel sources (tests/emu) proves indexing, ordering and arithmetic.  It cannot see what the gfx950
+compiler made of a kernel: a spill to scratch, a register count that halves the occupancy the launch was designed for, an
+LDS footprint that no longer lets two workgroups share a CU, or an instantiation whose main loop is not the one that was
+timed.  Those are read here from the assembly's metadata and instruction streams (tools/kernel_resources.py) - for every
+kernel of the product library, including the ones no GPU has run yet."""
+
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+
+LDS_PER_CU = 160 * 1024
+
+
+@pytest.fixture(scope="module")
+def code(tmp_path_factory):
+    import kernel_resources as kr
+
+    data = kr.collect(str(tmp_path_factory.mktemp("asm")))
+    rows = {}
+    for src, (text, rr) in data.items():
+        for r in rr:
+            rows[r["pretty"]] = dict(r, text=text)
+    return rows
+
+
+def test_no_kernel_spills_and_every_kernel_fits_a_cu(code):
+    assert len(code) > 60  # the table really was parsed
+    for name, r in code.items():
+        assert r["scratch"] == 0, (name, "spills to scratch")
+        assert r["vgpr"] <= 512 and r["agpr"] <= 256, name
+        assert r["lds"] <= LDS_PER_CU, name
+        # no scratch_* instruction in the stream either
+        import kernel_resources as kr
+
+        assert kr.count_classes(kr.kernel_lines(r["text"], r["name"]))["scratch"] == 0, name
+
+
+def test_mfma_gemm_kernels_keep_two_workgroups_per_cu(code):
+    """__launch_bounds__(256, 2): 8 waves per CU = 2 per SIMD -> at most 256 unified registers per lane and half the LDS
+    each.  The trailing update's look-ahead schedule (a panel chain next to it) and the XCD-aware grid sizing both
+    assume two resident workgroups."""
+    gemms = {n: r for n, r in code.items() if n.startswith("gemm_nt_kernel<")}
+    assert {"gemm_nt_kernel<128, 128, 0, 0>", "gemm_nt_kernel<128, 128, 2, 0>", "gemm_nt_kernel<128, 128, 3, 0>",
+            "gemm_nt_kernel<128, 64, 0, 0>", "gemm_nt_kernel<128, 64, 1, 0>", "gemm_nt_kernel<64, 64, 0, 0>",
+            "gemm_nt_kernel<64, 64, 1, 0>"} <= set(gemms)
+    for name, r in gemms.items():
+        assert r["vgpr"] <= 256, (name, r["vgpr"])
+        assert r["lds"] <= 80 * 1024, (name, r["lds"])
+        assert r["wg"] == 256, name
+
+
+def test_every_gemm_instantiation_has_the_measured_kernels_main_loop(code):
+    """`gemm_nt_kernel<128,128,2>` (the Cholesky's trailing update) is the one with rocprof timings on record (0.84 of the
+    fp64 MFMA peak at N = 131 072).  MODE 3 (`C += A B^T`, step (B) of the gradient) and MODE 0 have never been timed
+    alone: their steady-state k-loop must be the same loop - same MFMA / LDS-read / LDS-write / global-load / barrier
+    counts per 16-deep step - and differ only in the epilogue (C read + stores instead of atomics)."""
+    import kernel_resources as kr
+
+    def prof(name):
+        return kr.loop_profile(code[name]["text"], code[name]["name"])
+
+    ref = prof("gemm_nt_kernel<128, 128, 2, 0>")
+    # 128 x 128 tile, 4 waves of 64 x 64 (4 x 4 MFMA tiles of 16 x 16 x 4, four k-quarters of a 16-deep step), one barrier
+    assert ref["loop"]["mfma"] == 64 and ref["loop"]["barrier"] == 1 and ref["loop"]["global_load"] == 8
+    assert ref["loop"]["global_atomic"] == 0 and ref["loop"]["global_store"] == 0  # nothing leaves the loop
+    assert ref["total"]["global_atomic"] == 64 and ref["total"]["global_store"] == 0  # the atomic epilogue: no C read
+    for other in ("gemm_nt_kernel<128, 128, 3, 0>", "gemm_nt_kernel<128, 128, 0, 0>"):
+        p = prof(other)
+        for k in ("mfma", "lds_read", "lds_write", "global_load", "barrier", "global_store", "global_atomic"):
+            assert p["loop"][k] == ref["loop"][k], (other, k, p["loop"], ref["loop"])
+        assert abs(p["loop_lines"] - ref["loop_lines"]) <= 8, (other, p["loop_lines"], ref["loop_lines"])
+        # epilogue: reads the C tile once (64 more loads than the loop's operands) and writes it once
+        assert p["total"]["global_store"] == 64 and p["total"]["global_atomic"] == 0
+        assert p["total"]["global_load"] == ref["total"]["global_load"] + 64
+    # the narrower tilings scale the same loop
+    for name, mfma in (("gemm_nt_kernel<128, 64, 0, 0>", 32), ("gemm_nt_kernel<128, 64, 1, 0>", 32), ("gemm_nt_kernel<64, 64, 0, 0>", 16),
+                       ("gemm_nt_kernel<64, 64, 1, 0>", 16)):
+        p = prof(name)
+        assert p["loop"]["mfma"] == mfma and p["loop"]["barrier"] == 1, (name, p["loop"])
+
+
+def test_kernels_new_since_the_last_hardware_contact_are_small_and_clean(code):
+    """block_copy / grad_reduce / grad_finish / flag_* / check_sorted / diag_out<32>: first run on hardware is still ahead.
+    Their static footprint is what the design assumed (they run between MFMA launches and must not evict them)."""
+    for name, vg, lds in (("block_copy_kernel<true>", 32, 34 * 1024), ("block_copy_kernel<false>", 32, 0), ("grad_finish_kernel", 32, 8192),
+                          ("flag_store_kernel", 8, 0), ("flag_merge_kernel", 8, 0), ("check_sorted_kernel", 16, 0), ("diag_out_kernel<32>", 32, 9 * 1024)):
+        r = code[name]
+        assert r["vgpr"] <= vg and r["lds"] <= lds, (name, r["vgpr"], r["lds"])
+    for kid in range(4):
+        r = code[f"grad_reduce_kernel<{kid}>"]
+        assert r["vgpr"] <= 128 and r["lds"] <= 4096, (kid, r["vgpr"], r["lds"])  # >= 4 waves per SIMD for an HBM-bound scan
+    # the default training fill (rows contiguous, U columns per thread): >= 4 waves per SIMD too
+    for name, r in code.items():
+        if re.match(r"fill_kernel<\d, 4, 0, 4>", name):
+            assert r["vgpr"] <= 128, (name, r["vgpr"])
