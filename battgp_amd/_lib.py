@@ -65,6 +65,10 @@ SIGNATURES = {
         [handle_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_double],
     ),
     "bgp_aug_rows_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]),
+    "bgp_cross_block_dev": (
+        C.c_int,
+        [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int64],
+    ),
     "bgp_factor_panel_dev": (C.c_int, [handle_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, c_int_p]),
     "bgp_factor_pack_panel_dev": (
         C.c_int,

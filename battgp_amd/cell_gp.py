@@ -383,8 +383,16 @@ class BatteryCellGP:
         if xq.ndim == 1:
             xq = xq.reshape(-1, self._train_inputs[0].shape[1])
         if self.n_devices > 1:
-            self.fit()
-            mean, var = self._shard().predict(xq.detach().cpu().numpy(), min_var=MIN_VARIANCE)
+            gp = self._shard()
+            if not self._fitted:  # the same fused first pass over the ranks' panels (ShardedExactGP.fit_predict)
+                gp.set_hyp(self.hyp_vector())
+                xt, yt = self._train_inputs[0], self._train_targets
+                self.lml, mean, var = gp.fit_predict(xt.detach().cpu().numpy(), yt.detach().cpu().numpy(), xq.detach().cpu().numpy(),
+                                                     min_var=MIN_VARIANCE)
+                self.jitter = gp.jitter
+                self._fitted = True
+            else:
+                mean, var = gp.predict(xq.detach().cpu().numpy(), min_var=MIN_VARIANCE)
             return torch.as_tensor(mean, device=xq.device), torch.as_tensor(var, device=xq.device)
         eng = self.engine()
         xt, yt = self._train_inputs[0], self._train_targets

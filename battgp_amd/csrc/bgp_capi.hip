@@ -1694,6 +1694,19 @@ int bgp_fill_block_dev(bgp_handle* h, const double* X_dev, int64_t N, int D, int
                      row0 == col0 ? 1 : 0, nv1, nv2);
 }
 
+int bgp_cross_block_dev(bgp_handle* h, const double* Xq_dev, int64_t M, int64_t nrows, const double* X_dev, int64_t N, int D,
+                        int64_t col0, int64_t ncols, double* out_dev, int64_t ld) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!Xq_dev || !X_dev || !out_dev || M < 1 || nrows < M || col0 < 0 || ncols < 1 || ld < nrows)
+    return bgp_fail(h, -1, "bgp_cross_block_dev: bad arguments (M=%lld nrows=%lld ncols=%lld ld=%lld)", (long long)M, (long long)nrows,
+                    (long long)ncols, (long long)ld);
+  FillParams p;
+  if ((rc = make_fill_params(h, D, 0.0, &p))) return rc;
+  // (x pointers are only dereferenced for indices < nvalid: an offset past N is never read)
+  return launch_fill(h, h->s_main, p, Xq_dev, nrows, X_dev + col0 * D, ncols, out_dev, ld, 0, 0, M, N > col0 ? N - col0 : 0);
+}
+
 int bgp_aug_rows_dev(bgp_handle* h, const double* y_dev, int64_t N, int64_t col0, int64_t ncols, double* aug_dev,
                      int64_t ld) {
   int rc = check_handle(h);

@@ -50,13 +50,17 @@ def round_up(v: int, q: int) -> int:
 
 
 class PanelLayout:
-    def __init__(self, n: int, nb: int, world: int):
+    def __init__(self, n: int, nb: int, world: int, ride: int = 0):
         if nb % 64 != 0 or nb < 64:
             raise ValueError("nb must be a positive multiple of 64")
-        self.n, self.nb, self.world = n, nb, world
+        if ride % 64 != 0 or ride < 0:
+            raise ValueError("ride must be a non-negative multiple of 64")
+        self.n, self.nb, self.world, self.ride = n, nb, world, ride
         self.npad = round_up(n, 64)
         self.npanels = -(-self.npad // nb)
-        self.nrows = self.npad + AUG  # rows of panel 0: the padded matrix + the augmented block
+        # rows of panel 0: the padded matrix + the augmented block (+ the cross-covariance rows of a fit_predict, which
+        # ride through the factorisation below it and come out as K_*X L^-T)
+        self.nrows = self.npad + AUG + ride
 
     def owner(self, j: int) -> int:
         return j % self.world
@@ -74,8 +78,12 @@ class PanelLayout:
         return [j for j in range(self.npanels) if j % self.world == rank]
 
     def rows_from(self, j: int) -> int:
-        """rows of panel j from its diagonal down, augmented block included"""
+        """rows of panel j from its diagonal down, augmented block (and riding rows) included"""
         return self.nrows - self.col0(j)
+
+    def sigma_rows(self, j: int) -> int:
+        """rows of panel j inside the matrix = offset of its augmented block; the riding rows start AUG further down"""
+        return self.npad - self.col0(j)
 
     def ld(self, j: int) -> int:
         """leading dimension of stored panel j: its own height (no rows above its diagonal block are kept), bumped off
@@ -141,16 +149,23 @@ class DeviceBackend:
         return C.c_void_p(t.data_ptr() + 8 * int(off))
 
     # ---- factorisation ------------------------------------------------------------------------------
-    def fill_panel(self, store, off, ld, x_dev, n, d, col0, ncols, rows, y_dev, extra_diag):
-        """panel [rows, ncols] at store[off:], leading dimension ld: Sigma rows [col0, npad) of columns
-        [col0, col0 + ncols), then the augmented block"""
+    def fill_panel(self, store, off, ld, x_dev, n, d, col0, ncols, nsig, y_dev, extra_diag):
+        """panel at store[off:], leading dimension ld: the nsig Sigma rows [col0, npad) of columns [col0, col0 + ncols),
+        then the augmented block"""
         self._chk(
-            self.lib.bgp_fill_block_dev(self.h, self._p(x_dev), n, d, col0, col0, rows - AUG, ncols, self._p(store, off), ld, float(extra_diag)),
+            self.lib.bgp_fill_block_dev(self.h, self._p(x_dev), n, d, col0, col0, nsig, ncols, self._p(store, off), ld, float(extra_diag)),
             "bgp_fill_block_dev",
         )
         self._chk(
-            self.lib.bgp_aug_rows_dev(self.h, self._p(y_dev), n, col0, ncols, self._p(store, off + rows - AUG), ld),
+            self.lib.bgp_aug_rows_dev(self.h, self._p(y_dev), n, col0, ncols, self._p(store, off + nsig), ld),
             "bgp_aug_rows_dev",
+        )
+
+    def ride_fill(self, store, off, ld, xq_dev, m, nrows, x_dev, n, d, col0, ncols):
+        """the riding block [nrows, ncols] at store[off:]: k(xq_i, x_j) for the panel's columns, zero in the padding"""
+        self._chk(
+            self.lib.bgp_cross_block_dev(self.h, self._p(xq_dev), m, nrows, self._p(x_dev), n, d, col0, ncols, self._p(store, off), ld),
+            "bgp_cross_block_dev",
         )
 
     def flag_reset(self):
@@ -191,10 +206,10 @@ class DeviceBackend:
         self._chk(self.lib.bgp_diag_logsum_dev(self.h, self._p(store, off), ld, nbk, C.byref(out)), "bgp_diag_logsum_dev")
         return float(out.value)
 
-    def aug_row(self, store, off, ld, rows, nbk):
-        """z segment = row 0 of the augmented block under the panel (strided view, copied)"""
+    def aug_row(self, store, off, ld, nsig, nbk):
+        """z segment = row 0 of the augmented block under the panel's nsig matrix rows (strided view, copied)"""
         with self.on_stream():
-            return store.as_strided((nbk,), (ld,), off + rows - AUG).clone()
+            return store.as_strided((nbk,), (ld,), off + nsig).clone()
 
     # ---- collectives (issued with the engine's stream current) ------------------------------------------
     def bcast_start(self, dist, t, src):
@@ -293,9 +308,9 @@ class DeviceBackend:
         self._chk(self.lib.bgp_var_finish_dev(self.h, self._p(xq_dev), m, d, self._p(ssq), float(min_var), self._p(out)), "bgp_var_finish_dev")
         return out
 
-    def rowdot(self, e, lde, m, n, vec, voff, out):
+    def rowdot(self, e, lde, m, n, vec, voff, out, eoff=0):
         self._chk(
-            self.lib.bgp_rowdot_dev(self.h, self._p(e), lde, m, n, self._p(vec, voff) if vec is not None else None, self._p(out)),
+            self.lib.bgp_rowdot_dev(self.h, self._p(e, eoff), lde, m, n, self._p(vec, voff) if vec is not None else None, self._p(out)),
             "bgp_rowdot_dev",
         )
 
@@ -390,9 +405,9 @@ class ShardedExactGP:
             self.engine = None
 
     # ---- fit ------------------------------------------------------------------------------------
-    def _allocate(self, n: int, d: int):
-        lay = self.lay = PanelLayout(n, self.nb, self.world)
-        if self._shape == (n, d):
+    def _allocate(self, n: int, d: int, ride: int = 0):
+        lay = self.lay = PanelLayout(n, self.nb, self.world, ride)
+        if self._shape == (n, d, ride):
             return lay
         be = self.be
         mine = lay.local_panels(self.rank)
@@ -405,24 +420,66 @@ class ShardedExactGP:
         nslots = -(-lay.npanels // self.world)
         per_buf = max(lay.nb * lay.nrows + 1, self.world * nslots * lay.nb * lay.nb)
         self.pbufs = [be.empty(per_buf), be.empty(per_buf)]
-        self.sbuf = be.empty(nslots * lay.nb * lay.nb) if self.world > 1 else None  # this rank's pieces of one row block
+        self.sbuf = be.empty(nslots * lay.nb * lay.nb) if self.dist is not None else None  # this rank's pieces of one row block
         self.wk = [be.empty(lay.nb * lay.nb) for _ in range(4)]  # nb x nb work blocks of the gradient
-        self._shape = (n, d)
+        self._shape = (n, d, ride)
         return lay
 
     def fit(self, x: np.ndarray, y: np.ndarray) -> float:
         t_start = time.perf_counter()
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
-        n, d = x.shape
-        be = self.be
-        self._allocate(n, d)
-        self.n, self.d = n, d
-        self.x_dev, self.y_dev = be.upload(x), be.upload(y)
+        self._upload(x, y, None)
         self._phase = "fit"
         self._fit_resident()
         self._times["fit_s"] = time.perf_counter() - t_start
         return self.lml
+
+    def _upload(self, x, y, xq):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        n, d = x.shape
+        be = self.be
+        self._xq_dev, self._m = None, 0
+        ride = 0
+        if xq is not None:
+            xq = np.ascontiguousarray(xq, dtype=np.float64)
+            self._m = xq.shape[0]
+            ride = round_up(self._m, 64)
+        self._allocate(n, d, ride)
+        self.n, self.d = n, d
+        self.x_dev, self.y_dev = be.upload(x), be.upload(y)
+        if xq is not None:
+            self._xq_dev = be.upload(xq)
+
+    def fit_predict(self, x: np.ndarray, y: np.ndarray, xq: np.ndarray, min_var: float = 1e-10):
+        """Fit and the first prediction in ONE pass over the panels - the sharded form of ``bgp_fit_predict``, which is the
+        reference's actual flow (the model is built lazily and the first ``predict`` triggers the factorisation,
+        ``src/batt_models/battcellgp_full.py:171-173``): the cross-covariance rows ``K(xq, X)`` are appended below the
+        augmented block of every panel and ride through the factorisation, so ``V^T = K_*X L^-T`` comes out of the
+        Cholesky itself, spread over the owners of the panels.  ``mean = V^T z`` and ``var = k_** - rowsumsq(V^T)`` are
+        local row-dots per panel + two small all-reduces: no right-looking pass over the factor, no per-panel reduce, and
+        the ``M N^2`` flop of the solve run inside the rank-``nb`` updates, spread over all ranks.  Each broadcast grows
+        by ``M_pad x nb`` doubles.  Returns ``(lml, mean, var)``, identical on every rank; the model stays fitted
+        (:meth:`predict` with other queries walks the stored factor)."""
+        t_start = time.perf_counter()
+        self._upload(x, y, xq)
+        self._phase = "fit"
+        self._fit_resident()
+        lay, be = self.lay, self.be
+        m, ride = self._m, lay.ride
+        mean_p, var_p, tmp = be.zeros(ride), be.zeros(ride), be.zeros(ride)
+        for j in lay.local_panels(self.rank):
+            c0, w = lay.col0(j), lay.width(j)
+            eoff = self.poff[j] + lay.sigma_rows(j) + AUG  # V^T[:, panel j]: [ride, w], leading dimension of the panel
+            be.rowdot(self.store, lay.ld(j), ride, w, self.z, c0, tmp, eoff=eoff)
+            be.add_into(mean_p, tmp)
+            be.rowdot(self.store, lay.ld(j), ride, w, None, 0, tmp, eoff=eoff)
+            be.add_into(var_p, tmp)
+        self._allreduce(mean_p)
+        self._allreduce(var_p)
+        mean = be.to_host(mean_p)[:m]
+        var = be.to_host(be.var_finish(self._xq_dev, m, self.d, var_p, min_var))[:m]
+        self._times["fit_predict_s"] = time.perf_counter() - t_start
+        return self.lml, mean, var
 
     def _fit_resident(self) -> float:
         """fill + jittered factorisation + z + LML on the resident inputs"""
@@ -433,7 +490,10 @@ class ShardedExactGP:
         for attempt in range(self.max_tries + 1):
             be.flag_reset()
             for j in mine:
-                be.fill_panel(self.store, self.poff[j], lay.ld(j), self.x_dev, n, d, lay.col0(j), lay.width(j), lay.rows_from(j), self.y_dev, jitter)
+                be.fill_panel(self.store, self.poff[j], lay.ld(j), self.x_dev, n, d, lay.col0(j), lay.width(j), lay.sigma_rows(j), self.y_dev, jitter)
+                if lay.ride:
+                    be.ride_fill(self.store, self.poff[j] + lay.sigma_rows(j) + AUG, lay.ld(j), self._xq_dev, self._m, lay.ride,
+                                 self.x_dev, n, d, lay.col0(j), lay.width(j))
             self._enqueue_factorisation()
             info = self._collect_flag()  # the ONE host synchronisation of the attempt
             if info == 0:
@@ -450,7 +510,7 @@ class ShardedExactGP:
         logdet = 0.0
         for j in mine:
             c0, w = lay.col0(j), lay.width(j)
-            be.set_segment(z, c0, be.aug_row(self.store, self.poff[j], lay.ld(j), lay.rows_from(j), w))
+            be.set_segment(z, c0, be.aug_row(self.store, self.poff[j], lay.ld(j), lay.sigma_rows(j), w))
             logdet += be.diag_logsum(self.store, self.poff[j], lay.ld(j), w)
         ld_t = be.scalar(logdet)
         self._allreduce(z)

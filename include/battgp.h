@@ -266,6 +266,14 @@ int bgp_fill_dev(bgp_handle* h, const double* x1_dev, int64_t n1, const double* 
 int bgp_fill_block_dev(bgp_handle* h, const double* X_dev, int64_t N, int D, int64_t row0, int64_t col0,
                        int64_t nrows, int64_t ncols, double* out_dev, int64_t ld, double extra_diag);
 
+/* Cross-covariance rows that RIDE through a sharded factorisation below the augmented block of a panel (the sharded form
+ * of bgp_fit_predict's riding rows): out[i + (j-col0)*ld] = k(xq_i, x_j) for i < M and j < N, zero for the padding rows
+ * i in [M, nrows) and padding columns j >= N;  j in [col0, col0+ncols).  No noise term.  After the panel's factorisation
+ * and the updates by the earlier panels these rows hold (K_*X L^-T)[:, panel] - src/batt_models/battcellgp_full.py:171-173
+ * evaluated without a separate triangular-solve pass. */
+int bgp_cross_block_dev(bgp_handle* h, const double* Xq_dev, int64_t M, int64_t nrows, const double* X_dev, int64_t N, int D,
+                        int64_t col0, int64_t ncols, double* out_dev, int64_t ld);
+
 /* Augmented block under columns [col0, col0+ncols): aug[r + (j-col0)*ld] = (r == 0 && j < N) ? y[j] : 0,
  * r < 64.  After the factorisation row 0 holds z^T = (L^-1 y)^T for those columns. */
 int bgp_aug_rows_dev(bgp_handle* h, const double* y_dev, int64_t N, int64_t col0, int64_t ncols,

@@ -97,19 +97,28 @@ def test_fused_equals_separate(P, n, m):
 
 
 @pytest.mark.parametrize("kid", [0, 1, 2, 3])
-def test_lml_gradient_vs_oracle(P, kid):
-    P.test_lml_gradient_matches_oracle(kid, 24)
+def test_lml_gradient_vs_oracle(emu, kid):
+    _load("test_gpu_grad").test_lml_gradient_matches_oracle(kid, 24)
+
+
+def test_gradient_bookkeeping(emu):
+    """phase-time slots around a gradient and the opt-in kept factor (tests/test_gpu_grad.py; the block-bounds test of the
+    same module needs torch "device" tensors and runs under `pytest --emu` / on the GPU)"""
+    G = _load("test_gpu_grad")
+    G.test_restoring_the_factor_does_not_overwrite_the_fits_phase_times()
+    G.test_keep_factor_brings_the_factor_back_by_a_copy(512)
 
 
 @pytest.mark.parametrize("name,n", [("k2", 400), ("k2b", 64), ("k3", 64), ("k1", 10)])
 def test_scikit_learn_pins_through_the_kernels(emu, golden_dir, name, n):
     """LML, analytic gradient and latent posterior of the Matern / RBF kernels against the scikit-learn pins"""
     _load("test_gpu_pins_and_sizes").test_matern_and_rbf_match_scikit_learn_pins(golden_dir, name, n)
+    _load("test_gpu_grad").test_gradient_matches_scikit_learn_pins(golden_dir, name, n)
 
 
 @pytest.mark.parametrize("name,n", [("k0prod", 256), ("k0test", 64), ("k1", 10)])
 def test_autograd_gradient_pins_through_the_kernels(emu, golden_dir, name, n):
-    _load("test_gpu_pins_and_sizes").test_lml_gradient_matches_torch_autograd_pins(golden_dir, name, n)
+    _load("test_gpu_grad").test_lml_gradient_matches_torch_autograd_pins(golden_dir, name, n)
 
 
 def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):

@@ -42,13 +42,25 @@ def test_sharded_single_rank_matches_oracle_and_engine(n, nb):
     assert np.allclose(grad, g_eng, rtol=1e-6), (grad, g_eng)
     mean_b, var_b = gp.predict(xq)
     assert np.array_equal(mean_b, mean) and np.array_equal(var_b, var)
+    # fit + first prediction in ONE pass: the query rows ride through the panels (bgp_cross_block_dev); same LML bit
+    # for bit (the riding rows do not touch the matrix), posterior within the parity tolerance (other summation order);
+    # later queries and the gradient work on the store that carries the riding rows
+    lml_f, mean_f, var_f = gp.fit_predict(x, y, xq)
+    assert lml_f == lml
+    assert np.linalg.norm(mean_f - m_ref) < 1e-6 * np.linalg.norm(m_ref)
+    assert np.max(np.abs(var_f - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+    mean_c, var_c = gp.predict(xq[:20])
+    assert np.array_equal(mean_c, mean[:20]) and np.array_equal(var_c, var[:20])
+    assert np.allclose(gp.lml_grad(), grad, rtol=1e-12)
     # a second fit on the same object (resident buffers, new hyper-parameters) and the timers
     hyp2 = synthetic.HYP_BATTGP.copy()
     hyp2[2] *= 2.0
     gp.set_hyp(hyp2)
+    with pytest.raises(RuntimeError, match="fit first"):
+        gp.predict(xq)
     lml2 = gp.fit(x, y)
     assert abs(lml2 - OracleGP(K.KERNEL_BATTGP, hyp2, x, y).fit().lml) < 1e-6 * abs(lml2)
-    assert set(gp.timers()) == {"fit_s", "predict_s", "grad_s"}
+    assert set(gp.timers()) == {"fit_s", "predict_s", "grad_s", "fit_predict_s"}
     gp.close()
 
 
@@ -110,6 +122,10 @@ def _two_rank_worker(rank, world, port, n, nb, q):
     lml = gp.fit(x, y)
     mean, var = gp.predict(xq)
     grad = gp.lml_grad()
+    lml_f, mean_f, var_f = gp.fit_predict(x, y, xq)  # the fused pass: riding rows, no right-looking prediction pass
+    assert lml_f == lml
+    assert np.linalg.norm(mean_f - mean) < 1e-8 * np.linalg.norm(mean) and np.max(np.abs(var_f - var)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
+    assert "reduce" not in gp.comm_bytes().get("fit", {}) and gp.comm_bytes()["predict"]["reduce"][0] == gp.lay.npanels
     q.put((rank, lml, mean.tolist(), var.tolist(), grad.tolist()))
     parallel.barrier(gp.dist)
     dist = gp.dist

@@ -51,8 +51,8 @@ class NumpyBackend:
         return np.lib.stride_tricks.as_strided(buf[off:], (rows, cols), (8, 8 * ld))
 
     # ---- factorisation ----
-    def fill_panel(self, store, off, ld, x, n, d, col0, ncols, rows, y, extra_diag):
-        nr = rows - 64
+    def fill_panel(self, store, off, ld, x, n, d, col0, ncols, nsig, y, extra_diag):
+        nr = nsig
         blk = np.zeros((nr, ncols))
         idx_r = np.arange(col0, col0 + nr)
         idx_c = np.arange(col0, col0 + ncols)
@@ -66,6 +66,14 @@ class NumpyBackend:
         a = np.zeros((64, ncols))
         a[0, vc] = y[idx_c[vc]]
         self._cm(store, off + nr, 64, ncols, ld)[:] = a
+
+    def ride_fill(self, store, off, ld, xq, m, nrows, x, n, d, col0, ncols):
+        blk = np.zeros((nrows, ncols))
+        idx_c = np.arange(col0, col0 + ncols)
+        vc = idx_c < n
+        if vc.any():
+            blk[:m, vc] = self.K.kernel_matrix(self.kid, self.hyp, xq[:m], x[idx_c[vc]])
+        self._cm(store, off, nrows, ncols, ld)[:] = blk
 
     def flag_reset(self):
         self.flag = 0
@@ -101,8 +109,8 @@ class NumpyBackend:
     def diag_logsum(self, store, off, ld, nbk):
         return float(np.sum(np.log(np.diag(self._cm(store, off, nbk, nbk, ld)))))
 
-    def aug_row(self, store, off, ld, rows, nbk):
-        return self._cm(store, off + rows - 64, 1, nbk, ld)[0].copy()
+    def aug_row(self, store, off, ld, nsig, nbk):
+        return self._cm(store, off + nsig, 1, nbk, ld)[0].copy()
 
     # ---- collectives: numpy buffers wrapped in place ----
     def _t(self, a):
@@ -147,8 +155,8 @@ class NumpyBackend:
         var = self.K.kernel_diag(self.kid, self.hyp, xq) - ssq[:m]
         return np.maximum(var, min_var) if min_var >= 0 else var
 
-    def rowdot(self, e, lde, m, n, vec, voff, out):
-        em = self._cm(e, 0, m, n, lde)
+    def rowdot(self, e, lde, m, n, vec, voff, out, eoff=0):
+        em = self._cm(e, eoff, m, n, lde)
         out[:m] = em @ vec[voff : voff + n] if vec is not None else np.einsum("ij,ij->i", em, em)
 
     def add_into(self, acc, t):
@@ -245,6 +253,15 @@ def _worker(rank, world, port, n, nb, q):
     comm["grad"] = gp.comm_bytes(reset=True)
     mean2, var2 = gp.predict(xq)    # ... and the next prediction gets it back
     assert np.array_equal(mean, mean2) and np.array_equal(var, var2)
+    gp.comm_bytes(reset=True)
+    # fit + first prediction in one pass: the query rows ride through the factorisation (no right-looking pass, no reduce)
+    lml_fp, mean_fp, var_fp = gp.fit_predict(x, y, xq)
+    comm["fit_predict"] = gp.comm_bytes(reset=True)
+    mean3, var3 = gp.predict(xq[:7])  # later queries walk the stored factor (which carries the riding rows along)
+    assert np.allclose(mean3, mean_fp[:7], rtol=1e-9, atol=1e-12) and np.allclose(var3, var_fp[:7], rtol=1e-7, atol=1e-12)
+    grad_fp = gp.lml_grad()         # and the gradient works on a store with riding rows
+    assert np.allclose(grad_fp, grad, rtol=1e-9)
+    gp.comm_bytes(reset=True)
     gp.set_hyp(synthetic.HYP_BATTGP)  # new hyper-parameters leave the model unfitted, like bgp_set_kernel
     for call in (lambda: gp.predict(xq), gp.lml_grad):
         try:
@@ -252,7 +269,7 @@ def _worker(rank, world, port, n, nb, q):
             raise AssertionError("a call on an unfitted sharded model went through")
         except RuntimeError as e:
             assert "fit first" in str(e)
-    q.put((rank, lml, mean.tolist(), var.tolist(), grad.tolist(), comm))
+    q.put((rank, lml, mean.tolist(), var.tolist(), grad.tolist(), comm, lml_fp, mean_fp.tolist(), var_fp.tolist()))
     if dist is not None:
         parallel.barrier(dist)
         dist.destroy_process_group()
@@ -291,7 +308,11 @@ def _expected_comm(n, nb, world, rank, m, nhyp):
     ga_b = [8 * lay.width(k) * (npad - lay.col0(k)) for k in range(lay.npanels)]
     red = [8 * lay.width(k) * mpad for k in range(lay.npanels)]
     chunks = [8 * (-(-(k + 1) // w)) * nb * lay.width(k) for k in range(lay.npanels)]
+    ride = -(-m // 64) * 64
+    fp_b = [8 * (lay.width(k) * (lay.rows_from(k) + ride) + 1) for k in range(lay.npanels)]
     return {
+        # the fused call: the panels are `ride` rows taller, mean and variance are two more small all-reduces, NO reduce
+        "fit_predict": {"fit": {"broadcast": bcasts(fp_b), "all_reduce": allreduces([8, 8 * npad, 8, 8 * ride, 8 * ride])}},
         "fit": {"fit": {"broadcast": bcasts(fit_b), "all_reduce": allreduces([8, 8 * npad, 8])}},  # flag, z, log det
         "predict": {"predict": {"reduce": (len(red), sum(red), sum(sz * (w - 1) // w for sz in red)),
                                 "all_reduce": allreduces([8 * mpad, 8 * mpad])}},
@@ -332,7 +353,10 @@ def test_sharded_gp_matches_oracle(world, n, nb):
     from oracle.exact_gp import lml_and_grad
 
     _, g_ref = lml_and_grad(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, x, y)
-    for rank, lml, mean, var, grad, comm in res:
+    for rank, lml, mean, var, grad, comm, lml_fp, mean_fp, var_fp in res:
+        assert abs(lml_fp - ref.lml) < 1e-9 * abs(ref.lml)
+        assert np.linalg.norm(np.array(mean_fp) - m_ref) < 1e-8 * np.linalg.norm(m_ref)
+        assert np.max(np.abs(np.array(var_fp) - v_ref)) < 1e-9 * synthetic.OUTPUTSCALE_RBF
         # the exchange is what DESIGN.md section 6 says it is: call counts, payloads and per-rank received bytes
         assert comm == _expected_comm(n, nb, world, rank, 21, len(grad)), (rank, comm)
         assert abs(lml - ref.lml) < 1e-9 * abs(ref.lml), (rank, lml, ref.lml)
@@ -341,7 +365,7 @@ def test_sharded_gp_matches_oracle(world, n, nb):
         # the analytic gradient of the sharded model (the reference's ONE backward pass, src/gp/training.py:39-41);
         # entries span 20 orders of magnitude: each relative to itself
         assert np.allclose(np.array(grad), g_ref, rtol=1e-6), (rank, grad, g_ref)
-    assert res[0][1:5] == res[1][1:5]  # every rank ends with identical results
+    assert res[0][1:5] == res[1][1:5] and res[0][6:] == res[1][6:]  # every rank ends with identical results
 
 
 def test_panel_layout():
