@@ -413,11 +413,11 @@ int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t
   if (nblocks > 0x7fffffffLL) return -1;
   const int vec_ok = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   dim3 grid((unsigned)nblocks), block(256);
-  static const int unr = getenv("BGP_FILL_UNROLL") ? atoi(getenv("BGP_FILL_UNROLL")) : 0;  // experiment knob
 #define FILL_UNR(U)                                                                                          \
   hipLaunchKernelGGL((fill_kernel<KID, 4, 0, U>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag, \
                      nv1, nv2, nti, ntj, vec_ok)
-  // measured at N = 131 072 (steady GB/s by unroll 2 / 4 / 8 / 16): K0 5810 / 5750 / 5640 / 5780, Matern 5440 / 5570 / 5440 / 5470
+  // columns per thread and pass, measured at N = 131 072 (steady GB/s for 2 / 4 / 8 / 16): K0 5810 / 5750 / 5640 / 5780,
+  // Matern 5440 / 5570 / 5440 / 5470 - the winners are compiled in, the sweep's other instantiations and its knob are gone
   constexpr int UNR_DEFAULT = (KID == BGP_KERNEL_BATTGP) ? 2 : 4;
   static const bool t256 = getenv("BGP_FILL_TABLE") && atoi(getenv("BGP_FILL_TABLE")) == 256;  // experiment knob (A/B pending)
   static const bool fmfma = getenv("BGP_FILL_MFMA") && atoi(getenv("BGP_FILL_MFMA")) == 1;  // experiment knob (A/B pending)
@@ -430,10 +430,6 @@ int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t
   else if (p.D == 4 && t256)
     hipLaunchKernelGGL((fill_kernel<KID, 4, 4, UNR_DEFAULT>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag,
                        nv1, nv2, nti, ntj, vec_ok);
-  else if (p.D == 4 && unr == 2) FILL_UNR(2);
-  else if (p.D == 4 && unr == 4) FILL_UNR(4);
-  else if (p.D == 4 && unr == 8) FILL_UNR(8);
-  else if (p.D == 4 && unr == 16) FILL_UNR(16);
   else if (p.D == 4) FILL_UNR(UNR_DEFAULT);
   else
     hipLaunchKernelGGL((fill_kernel<KID, 0>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower,

@@ -100,5 +100,5 @@ def test_kernels_new_since_the_last_hardware_contact_are_small_and_clean(code):
         assert r["vgpr"] <= 128 and r["lds"] <= 4096, (kid, r["vgpr"], r["lds"])  # >= 4 waves per SIMD for an HBM-bound scan
     # the default training fill (rows contiguous, U columns per thread): >= 4 waves per SIMD too
     for name, r in code.items():
-        if re.match(r"fill_kernel<\d, 4, 0, 4>", name):
+        if re.match(r"fill_kernel<\d, 4, 0, \d+>", name):
             assert r["vgpr"] <= 128, (name, r["vgpr"])
