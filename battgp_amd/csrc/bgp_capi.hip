@@ -1991,11 +1991,11 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   PhaseTimer t(h, st, BGP_T_GRAD);
   h->factor_consumed = true;  // from here on the storage no longer holds a factor, whatever happens below
   // row block [K0, K0 + nbk) x columns [0, K0) of the stored triangle <-> its transpose Wt[0:K0, 0:nbk] (one launch per slab)
-  auto row_block = [&](int64_t K0, int64_t nbk, double* Wt, bool out) -> int {
+  auto row_block = [&](int64_t K0, int64_t nbk, double* Wt, bool out, double scale = 1.0) -> int {
     for (int64_t c_lo = 0; c_lo < K0;) {
       const int64_t c_hi = V.slab_end(c_lo, K0);
-      int r = out ? launch_block_copy(h, st, V.at(K0, c_lo), V.ld(c_lo), nbk, c_hi - c_lo, Wt + c_lo, ldt, 1, 1.0, 0)
-                  : launch_block_copy(h, st, Wt + c_lo, ldt, c_hi - c_lo, nbk, V.at(K0, c_lo), V.ld(c_lo), 1, 1.0, 0);
+      int r = out ? launch_block_copy(h, st, V.at(K0, c_lo), V.ld(c_lo), nbk, c_hi - c_lo, Wt + c_lo, ldt, 1, scale, 0)
+                  : launch_block_copy(h, st, Wt + c_lo, ldt, c_hi - c_lo, nbk, V.at(K0, c_lo), V.ld(c_lo), 1, scale, 0);
       if (r) return r;
       c_lo = c_hi;
     }
@@ -2034,7 +2034,11 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
     if ((rc = launch_copy_panel(h, st, Ms, NB, V.at(K0, K0), V.ld(K0), nbk, (int)nbk))) return rc;
   }
   // (B) P = M^T M = Sigma^-1 in place (lower triangle), row blocks from the top:  step k
-  //       P[0:K0, 0:K0] += M[k, 0:K0]^T M[k, 0:K0]       (rank-nb SYRK of the LEADING block per slab: the N^3/3 flop)
+  //       P[0:K0, 0:K0] += M[k, 0:K0]^T M[k, 0:K0]       (rank-nb SYRK of the LEADING block per slab: the N^3/3 flop;
+  //                                                        run as  P -= Wt1 (-Wt1)^T  on the SAME kernel and atomic
+  //                                                        epilogue as the Cholesky's trailing update and step (A) - the
+  //                                                        one with timings on record - against a negated second copy of
+  //                                                        the transposed row block: no C read, no third GEMM epilogue)
   //       M[k, 0:K0]    <- M_kk^T M[k, 0:K0]              (as Wt2 = Wt1 M_kk on the transposed row block)
   //       P_kk           = M_kk^T M_kk                    (the whole symmetric block is written)
   //     Row block k is untouched until its own step, and the leading block only collects finished contributions.
@@ -2043,9 +2047,11 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
     if ((rc = launch_block_copy(h, st, V.at(K0, K0), V.ld(K0), nbk, nbk, Mt, NB, 1, 1.0, 1))) return rc;  // M_kk^T
     if (K0 > 0) {
       if ((rc = row_block(K0, nbk, Wt1, true))) return rc;
+      if ((rc = row_block(K0, nbk, Wt2, true, -1.0))) return rc;  // Wt2 = -Wt1 (free until the transform below)
+      const int tmode = nbk >= 256 ? 2 : 0;
       for (int64_t c_lo = 0; c_lo < K0;) {
         const int64_t c_hi = V.slab_end(c_lo, K0);
-        if ((rc = launch_gemm_nt(h, st, 3, 128, V.at(c_lo, c_lo), V.ld(c_lo), Wt1 + c_lo, ldt, Wt1 + c_lo, ldt, K0 - c_lo,
+        if ((rc = launch_gemm_nt(h, st, tmode, 128, V.at(c_lo, c_lo), V.ld(c_lo), Wt1 + c_lo, ldt, Wt2 + c_lo, ldt, K0 - c_lo,
                                  c_hi - c_lo, nbk, 1)))
           return rc;
         c_lo = c_hi;
@@ -2076,7 +2082,7 @@ int bgp_gemm_nt_async_dev(bgp_handle* h, int mode, double* C_dev, int64_t ldc, c
                           const double* B_dev, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower, int btri) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (!C_dev || !A_dev || !B_dev || mode < 0 || mode > 3) return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: bad arguments (mode=%d)", mode);
+  if (!C_dev || !A_dev || !B_dev || mode < 0 || mode > 2) return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: bad arguments (mode=%d)", mode);
   if (btri && mode != 1) return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: btri needs mode 1");
   if (m < 0 || n < 0 || k < 0 || ldc < m || lda < m || ldb < n)
     return bgp_fail(h, -1, "bgp_gemm_nt_async_dev: bad shape m=%lld n=%lld k=%lld ldc=%lld lda=%lld ldb=%lld", (long long)m, (long long)n,

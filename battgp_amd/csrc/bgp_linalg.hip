@@ -4,7 +4,7 @@
 //     C[m,n] -= A[m,k] * B[n,k]^T        (MODE 0; `lower` keeps only tiles touching i >= j)
 //     C[m,n]  = A[m,k] * B[n,k]^T        (MODE 1; C may alias A: used as TRSM-by-inverse)
 //     C[m,n] += -(A B^T) by L2 atomics   (MODE 2; no C read: the deep rank-NB trailing updates)
-//     C[m,n] += A[m,k] * B[n,k]^T        (MODE 3; the accumulation steps of the in-place U U^T of the gradient)
+//   (the `C += A B^T` steps of the gradient's in-place M^T M run as MODE 2 / 0 against a negated copy of B)
 // built on v_mfma_f64_16x16x4_f64.  It serves the SYRK trailing update of the Cholesky, the
 // in-panel updates, the TRSM by inverted 64x64 diagonal tiles, the triangular solve of the
 // query block (posterior variance) and the full-covariance downdate.
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t j = j0 + wj * (TN / 2) + a * 16 + l4 + 4 * r;
-        acc[a][b][r] = ((MODE == 0 || MODE == 3) && i < m && j < n) ? C[i + j * ldc] : 0.0;
+        acc[a][b][r] = (MODE == 0 && i < m && j < n) ? C[i + j * ldc] : 0.0;
       }
     }
   }
@@ -1280,9 +1280,6 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
                        (int)k, lower, nti, ntj, abort_flag, btri);
   else if (tn == 128 && mode == 2)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
-                       (int)k, lower, nti, ntj, abort_flag, btri);
-  else if (tn == 128 && mode == 3)
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 3>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,
                        (int)k, lower, nti, ntj, abort_flag, btri);
   else if (tn == 64 && mode == 0)
     hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, m, n,

@@ -244,7 +244,7 @@ class DeviceBackend:
 
     # ---- gradient: Sigma^-1 in place over the distributed factor ------------------------------------------
     def gemm(self, mode, c, coff, ldc, a, aoff, lda, b, boff, ldb, m, n, k, lower=0, btri=0):
-        """C (op)= A B^T on the MFMA kernel: mode 0 ``-=``, 1 ``=``, 2 ``-=`` by atomics (deep k), 3 ``+=``"""
+        """C (op)= A B^T on the MFMA kernel: mode 0 ``-=``, 1 ``=``, 2 ``-=`` by atomics (deep k)"""
         self._chk(
             self.lib.bgp_gemm_nt_async_dev(self.h, mode, self._p(c, coff), ldc, self._p(a, aoff), lda, self._p(b, boff), ldb, m, n, k, lower, btri),
             "bgp_gemm_nt_async_dev",
@@ -400,7 +400,7 @@ class ShardedExactGP:
         eng = getattr(self, "engine", None)
         if eng is not None:
             self.be.sync()
-            self.store = self.pbufs = self.inv = self.z = None
+            self.store = self.pbufs = self.inv = self.z = self.nbuf = self.sbuf = None
             eng.close()
             self.engine = None
 
@@ -422,6 +422,7 @@ class ShardedExactGP:
         self.pbufs = [be.empty(per_buf), be.empty(per_buf)]
         self.sbuf = be.empty(nslots * lay.nb * lay.nb) if self.dist is not None else None  # this rank's pieces of one row block
         self.wk = [be.empty(lay.nb * lay.nb) for _ in range(4)]  # nb x nb work blocks of the gradient
+        self.nbuf, self._per_buf = None, per_buf  # the gradient's negated row block (allocated by the first lml_grad)
         self._shape = (n, d, ride)
         return lay
 
@@ -653,8 +654,9 @@ class ShardedExactGP:
             ``j <= k``) is assembled, transposed, into ``Wt[K1, nb]`` on every rank by ONE ALL-GATHER, issued one step
             ahead: each rank packs the pieces of ITS panels slot by slot (panel j -> slot j // world), the gathered
             chunks are put into the natural row order by one strided copy (panel = slot * world + rank); every rank adds
-            the rank-``nb`` SYRK ``P[J0:K0, j] += Wt[J0:K0] Wt[j]^T`` to its panels ``j < k``, transforms their row
-            block k (``M_kj <- M_kk^T M_kj``), the owner forms ``P_kk``.
+            the rank-``nb`` SYRK ``P[J0:K0, j] += Wt[J0:K0] Wt[j]^T`` to its panels ``j < k`` - run as ``-= Wt (-Wt)^T``
+            against a negated copy of the block, on the same kernel and atomic epilogue as the factorisation's updates -
+            transforms their row block k (``M_kj <- M_kk^T M_kj``), the owner forms ``P_kk``.
 
         ``alpha = M^T z`` is local per panel between (A) and (B); the reduction over each local panel's lower trapezoid
         re-evaluates the kernel derivatives, and ONE all-reduce of the few accumulators ends it.  Per rank: ``2/3 N^3 /
@@ -741,6 +743,9 @@ class ShardedExactGP:
         # block k+1 being packed while step k still reads block k.)
         self._phase = "grad_b"
         gathered = pbufs[1]
+        if self.nbuf is None:
+            self.nbuf = be.empty(self._per_buf)
+        wneg = self.nbuf
 
         def slots(k):
             return -(-(k + 1) // world)  # panels 0..k dealt round-robin: slots per rank
@@ -770,10 +775,14 @@ class ShardedExactGP:
                 be.unshuffle(gathered, wt, world, slots(k), nb, nbk)
             if k + 1 < lay.npanels:  # row block k+1 is untouched by step k: its exchange runs under this step's updates
                 work = gather(k + 1)
+            first = min((p for p in mine if p < k), default=None)
+            if first is not None:  # -Wt[J0:K0] from my first panel's rows on: the B operand of this step's SYRKs
+                F0 = lay.col0(first)
+                be.block_copy(wt, F0, ldw, K0 - F0, nbk, wneg, F0, ldw, scale=-1.0)
             for j in (p for p in mine if p < k):
                 J0, nbj = lay.col0(j), lay.width(j)
                 off, ld = self.poff[j], lay.ld(j)
-                be.gemm(3, self.store, off, ld, wt, J0, ldw, wt, J0, ldw, K0 - J0, nbj, nbk, lower=1)
+                be.gemm(2 if nbk >= 256 else 0, self.store, off, ld, wt, J0, ldw, wneg, J0, ldw, K0 - J0, nbj, nbk, lower=1)
                 be.gemm(1, t3, 0, nb, wt, J0, ldw, wt, K0, ldw, nbj, nbk, nbk)  # t3 = M_kj^T M_kk
                 be.block_copy(t3, 0, nb, nbj, nbk, self.store, off + (K0 - J0), ld, trans=1)
             if k in mine:

@@ -339,7 +339,8 @@ int bgp_update_panels_dev(bgp_handle* h, double* store_dev, const int64_t* desc,
 
 /* General form of the MFMA product  C[m, n] (op)= A[m, k] B[n, k]^T  (all column-major; k a multiple of 16; m, n, lda,
  * ldb even; A, B 16-byte aligned):  mode 0  C -= A B^T;  mode 1  C = A B^T (C must not overlap A or B unless n <= 64);
- * mode 2  C -= A B^T accumulated by one L2 atomic per element (no C read; deep k);  mode 3  C += A B^T.
+ * mode 2  C -= A B^T accumulated by one L2 atomic per element (no C read; deep k).  (A `C += A B^T` is mode 2 / 0 against
+ * a negated copy of B: bgp_block_copy_dev with scale -1.)
  * lower != 0: only tiles touching i >= j.  btri != 0 (mode 1): B is lower triangular (B[j, kk] = 0 for kk > j) and
  * the zero half of the k-range is skipped. */
 int bgp_gemm_nt_async_dev(bgp_handle* h, int mode, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,

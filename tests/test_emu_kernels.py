@@ -346,7 +346,7 @@ def test_optional_interior_paths_of_the_fill():
 def test_index_arithmetic_beyond_2_pow_32_elements():
     """tests/emu/huge_ld_check.py: small problems stored at a leading dimension of 2^25 (2^23) elements, so that every
     kernel's ``row + col * ld`` passes 2^31 and 2^32 - the sharded device path end to end (fill, factor + pack, updates,
-    prediction, in-place inverse, gradient reduction), the MFMA GEMM in all four modes, the block copies and the blocked
+    prediction, in-place inverse, gradient reduction), the MFMA GEMM in all three modes, the block copies and the blocked
     Cholesky driver under every look-ahead word - in seconds, without an N > 46 341 problem"""
     import subprocess
 

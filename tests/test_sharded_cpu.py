@@ -177,13 +177,13 @@ class NumpyBackend:
         cm = self._cm(c, coff, m, n, ldc)
         if lower:  # only the part on or below the diagonal is defined (the kernel works at tile granularity)
             keep = np.tril(np.ones((m, n), dtype=bool))
-            cm[keep] = (cm + prod)[keep] if mode == 3 else ((cm - prod)[keep] if mode in (0, 2) else prod[keep])
+            cm[keep] = (cm - prod)[keep] if mode in (0, 2) else prod[keep]
         elif mode in (0, 2):
             cm[:] -= prod
         elif mode == 1:
             cm[:] = prod
         else:
-            cm[:] += prod
+            raise ValueError(f"gemm mode {mode}")
 
     def block_copy(self, src, soff, lds, rows, cols, dst, doff, ldd, trans=0, scale=1.0, tri=0):
         blk = scale * self._cm(src, soff, rows, cols, lds)
