@@ -1238,6 +1238,7 @@ void bgp_destroy(bgp_handle* h) {
   if (h->s_aux) (void)hipStreamSynchronize(h->s_aux);
   if (h->s_copy) (void)hipStreamSynchronize(h->s_copy);
   if (h->s_bulk) (void)hipStreamSynchronize(h->s_bulk);
+  free_keep(h);  // a kept factor copy belongs to the problem that is ending: never parked
   {
     HandlePool& p = pool();
     std::lock_guard<std::mutex> lk(p.mu);

@@ -661,8 +661,9 @@ class ShardedExactGP:
         ``alpha = M^T z`` is local per panel between (A) and (B); the reduction over each local panel's lower trapezoid
         re-evaluates the kernel derivatives, and ONE all-reduce of the few accumulators ends it.  Per rank: ``2/3 N^3 /
         world`` flop, ~``4 N^2 (w-1)/w`` bytes received in each of (A) and (B) (:meth:`comm_bytes` counts them), no second
-        ``N^2`` buffer (the packed-panel buffers of the factorisation are reused).  The factor is consumed: the next
-        :meth:`predict` re-runs the factorisation on the resident inputs."""
+        ``N^2`` buffer (the packed-panel buffers of the factorisation are reused; one more panel-sized buffer holds the
+        negated row block of step (B)).  The factor is consumed: the next :meth:`predict` re-runs the factorisation on
+        the resident inputs."""
         if self.lml is None:
             raise RuntimeError("lml_grad: fit first (set_hyp() leaves the model unfitted)")
         if self._factor_consumed:

@@ -64,9 +64,9 @@ enum {
   BGP_T_TRAIL_LAUNCHES = 10, /* number of those trailing-update launches */
   BGP_T_TRAIL_UNION = 11, /* time during which at least one of them was running (they overlap on two streams) */
   BGP_T_GRAD = 12,    /* bgp_lml_grad: Sigma^-1 in place over the factor + the fused reduction pass */
-  BGP_T_RESTORE = 13, /* bringing the factor back after a gradient consumed it (copy under bgp_set_keep_factor, else a
-                         re-run of the fit on the resident data); 0 if the last call needed none.  The fit's own
-                         FILL / POTRF / SOLVE / TRAIL* slots are NOT touched by that re-run */
+  BGP_T_RESTORE = 13, /* the most recent bringing-back of the factor after a gradient consumed it (copy under
+                         bgp_set_keep_factor, else a re-run of the fit on the resident data); 0 = none since the last fit.
+                         The fit's own FILL / POTRF / SOLVE / TRAIL* slots are NOT touched by that re-run */
   BGP_T_COUNT = 14
 };
 
