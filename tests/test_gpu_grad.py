@@ -301,6 +301,7 @@ def test_gradient_reduction_block_reads_nothing_outside_the_described_block(nrow
         ta = torch.from_numpy(alpha).to("cuda")
         acc = torch.zeros(nacc, dtype=torch.float64, device="cuda")
         vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        torch.cuda.synchronize()  # the uploads and the zero fill ran on torch's stream; the engine has its own
         rc = lib.bgp_grad_reduce_block_dev(e._h, vp(tx), n, d, r0, nrows, ncols, vp(tp), ld, vp(ta), vp(acc), 0)
         assert rc == 0, lib.bgp_last_error(e._h)
         e.sync()
