@@ -12,7 +12,8 @@ Headline workload (N = 1): BASELINE configs[2], the largest single-GPU configura
 N = 131 072 - the size the north-star's kernel targets are quoted on.  configs[1] (N = 40 000, the reference kernel)
 rides along as `extra_configs`.
 
-N > 1 is launched by torch.distributed.run, one rank per GPU:
+N > 1 runs one rank per GPU under torch.distributed.run (the driver's launch); a bare `python bench.py --gpus N` launches
+itself that way (self_launch):
   --mode cells   (default)  every rank fits its OWN cell (the reference's "8-cell pack" = independent GPs,
                  src/batt_models/battgp_full.py:41-60); no data-path collective; weak scaling; value = whole-job GFLOP/s
   --mode sharded ONE GP of size --n sharded over the ranks (column-panel block-cyclic Cholesky, RCCL broadcast of
@@ -738,6 +739,31 @@ def run_sharded(args, rank, world, local_rank, n):
     return rec
 
 
+def self_launch(n_ranks: int) -> None:
+    """A bare `python bench.py --gpus N ...` with N > 1 (no launcher above it: WORLD_SIZE unset) becomes the launch the
+    contract names - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    <the command line as it was given>` - by replacing this process (exec: the launcher inherits stdout, so rank 0's ONE
+    JSON line is this command's output, its exit code is this command's exit code, and a caller's SIGTERM reaches the
+    launcher, which hands it to the ranks).  One process per GPU, as the reference does it (gp_runner.py:246-298).
+    "The command line as it was given" = sys.orig_argv from the first script on: interpreter flags are dropped, a wrapper
+    script in front of bench.py (tests/emu/run_script_emu.py in the CPU rehearsal) stays in front of every rank."""
+    import socket
+
+    orig = list(getattr(sys, "orig_argv", [])) or [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]
+    start = next((i for i in range(1, len(orig)) if orig[i].endswith(".py") and os.path.isfile(orig[i])), None)
+    prog = orig[start:] if start is not None else [os.path.abspath(__file__), *sys.argv[1:]]
+    # torch.distributed.run's argparse takes a bare --n for an ambiguous prefix of its own options: hand it on under its other name
+    prog = ["--size" if a == "--n" else "--size=" + a[4:] if a.startswith("--n=") else a for a in prog]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), *prog]
+    print(f"bench.py: --gpus {n_ranks} without a launcher: exec {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -794,10 +820,10 @@ def main() -> None:
     from battgp_amd import parallel
 
     rank, world, local_rank = parallel.env_rank_world()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # does not return: this process becomes the launcher
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(
-            f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
-        )
+        raise SystemExit(f"--gpus {args.gpus} under a launcher that started {world} rank(s) (WORLD_SIZE={world}): the two must agree")
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

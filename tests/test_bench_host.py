@@ -128,6 +128,42 @@ def test_the_drivers_multi_gpu_launch_of_bench_py_rehearsed_on_the_cpu_build():
     assert sh["lml"] == pytest.approx(OracleGP(KERNEL_MATERN32, synthetic.HYP_MATERN32, xs, ys).fit().lml, rel=1e-9)
 
 
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_a_bare_multi_gpu_invocation_launches_itself_under_torch_distributed_run():
+    """`python3 bench.py --gpus 2 ...` with NO launcher above it (WORLD_SIZE unset - the shape of the
+    driver's 1-GPU command with another N) must not exit: it re-executes itself under `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1` and rank 0 prints the ONE JSON line.  One process per GPU is the
+    reference's own shape (gp_runner.py:246-298).  Rehearsed on the CPU build (the wrapper stays in front of every rank)."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py", "--gpus", "2", "--backend", "gloo", "--share-gpu",
+           "--steps", "1", "--warmup", "0", "--n", "300", "--sharded-n", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["config"]["n"] == 300 and out["value"] > 0
+    assert out["config"]["parallelism"] == "2 independent cells"
+
+
+def test_self_launch_command_line(monkeypatch, tmp_path):
+    """bench.self_launch: the launcher line is the contract's, the script's own arguments follow unchanged (--n under its
+    other name: torch.distributed.run's parser trips over it), interpreter flags are dropped"""
+    import bench
+
+    seen = {}
+    monkeypatch.setattr(os, "execv", lambda exe, argv: seen.update(exe=exe, argv=argv))
+    monkeypatch.setattr(sys, "orig_argv", [sys.executable, "-u", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--n", "4096", "--steps", "2"])
+    bench.self_launch(4)
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[:6] == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4"]
+    assert a[6:8] == ["--master-addr", "127.0.0.1"] and a[8] == "--master-port" and 1024 < int(a[9]) < 65536
+    assert a[10:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "4096", "--steps", "2"]
+
+
 def test_guarded_sub_run_reports_instead_of_propagating(monkeypatch):
     """bench._guarded: result, exception and time-out of the sharded sub-run all come back as a value"""
     import time
