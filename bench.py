@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak (= 256 CU x 2.4 GHz x 128 flop/clk)
 PEAK_HBM_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PROFILE_TAG = "r02"  # profiles/<tag>_n<N>_<kernel>_summary.json: committed rocprofv3 PMC passes of this round
+PROFILE_TAG = "r05"  # profiles/<tag>_n<N>_<kernel>_summary.json: committed rocprofv3 PMC passes of this round
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -329,9 +329,30 @@ def profile_summary(n: int, kernel: str):
     return None, None
 
 
+def n_max_measured(n_max: int, kernel: str, m: int, slab: int, nb: int, limit_s: float) -> dict:
+    """BASELINE's "N_max per GPU", measured by THIS run: one cold fit+predict at the largest size one MI355X holds (the factor
+    in column slabs, bgp_set_layout) - tools/large_n.py in a child process with a time limit (its own session: a device
+    allocation that does not fit, or a run-away, costs this field only).  ~105 s at N = 274 432."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "large_n.py"), str(n_max), kernel, str(slab), str(m), str(nb), "1"]
+    t0 = time.perf_counter()
+    r = run_child(cmd, limit_s)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"tools/large_n.py {n_max} ended with rc {r.returncode}: {r.stderr[-250:]}")
+    rec = json.loads(lines[-1])
+    return {
+        "n": rec["n"], "fit_predict_s": rec["fit_predict_s"], "gflops": rec["gflops"], "potrf_tflops": rec["potrf_tflops"],
+        "frac_of_peak": rec["gflops"] / 1e3 / PEAK_FP64_MFMA_TFLOPS, "slab_width": rec["slab_width"], "nb_outer": rec["nb_outer"],
+        "factor_bytes": rec["factor_bytes"], "device_bytes": rec["device_bytes"], "hbm_total": rec["hbm_total"],
+        "residuals": rec["residuals"], "lml": rec["lml"], "jitter": rec["jitter"], "full_square_limit_n": 196000, "kernel": kernel,
+        "child_s": time.perf_counter() - t0,
+        "source": "measured by this run: ONE cold call of tools/large_n.py (includes the hipMalloc of the factor) in a child process",
+    }
+
+
 def n_max_from_profile():
-    """Largest N measured on one MI355X (column-slab layout of the factor, tools/large_n.py): the committed record,
-    not re-measured here (one fit at that size takes ~100 s)."""
+    """FALLBACK of n_max_measured (side budget spent, --no-extras, N > 1): the committed record of the largest N measured on
+    one MI355X (column-slab layout of the factor, tools/large_n.py) - a citation, labelled as one."""
     path = os.path.join(ROOT, "profiles", "r01_large_n.json")
     if not os.path.exists(path):
         return None
@@ -341,7 +362,7 @@ def n_max_from_profile():
     return {
         "n": best["n"], "fit_predict_s": best["fit_predict_s"], "gflops": best["gflops"], "slab_width": best["slab_width"],
         "factor_bytes": best["factor_bytes"], "residuals": best["residuals"], "full_square_limit_n": 196000,
-        "source": "profiles/r01_large_n.json (tools/large_n.py; not re-measured by this run)",
+        "source": "CITED, not measured by this run: profiles/r01_large_n.json (tools/large_n.py, round 1)",
     }
 
 
@@ -594,10 +615,34 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
             finally:
                 w.close()
 
+        def sweep_point(sn):
+            """one point of BASELINE's "vs N" curve: median of warm fused fit+predict calls, inputs resident in HBM"""
+            w = CellWorkload(sn, m, args.kernel, local_rank, sn, args)
+            try:
+                w.step()
+                ts = []
+                for _ in range(5 if sn <= 16384 else 3):
+                    t0 = time.perf_counter()
+                    w.step()
+                    ts.append(time.perf_counter() - t0)
+                dt, ph = float(np.median(ts)), w.eng.phase_times()
+                gf = algorithmic_flop(sn, m) / dt / 1e9
+                return {"n": sn, "ms": dt * 1e3, "gflops": gf, "frac_of_peak": gf / 1e3 / PEAK_FP64_MFMA_TFLOPS, "reps": len(ts),
+                        "potrf_ms": ph["potrf_ms"], "fill_ms": ph["fill_ms"], "lml": w.eng.lml, "jitter": w.eng.jitter}
+            finally:
+                w.close()
+
         side("fill_steady", fill_side, 20.0)
         extras = [side(f"extra_{en}_{ek}", lambda en=en, ek=ek: extra_config(en, ek), 10.0)
                   for en, ek in ((args.extra_n, "battgp"),) if en > 0 and not (en == n and ek == args.kernel)]
         out["extra_configs"] = [e for e in extras if e]
+        # BASELINE's metric is "... vs N": the curve below the headline size (~2 s of GPU time in all), the headline point from
+        # the timed region itself, N_max appended further down when it was measured
+        pts = [side(f"vs_n_{sn}", lambda sn=sn: sweep_point(sn), 5.0) for sn in args.sweep_n if 0 < sn < n]
+        gf0 = flop * args.steps / elapsed / 1e9
+        out["vs_n"] = [p for p in pts if p] + [{"n": n, "ms": elapsed / args.steps * 1e3, "gflops": gf0, "frac_of_peak": gf0 / 1e3 / PEAK_FP64_MFMA_TFLOPS,
+                                                 "reps": args.steps, "potrf_ms": rec["phases_ms"]["potrf_ms"], "fill_ms": rec["phases_ms"]["fill_ms"],
+                                                 "lml": lml, "jitter": jitter, "note": "the timed region of this run"}]
         trim_pool(local_rank)  # the children below need the HBM
         # required field before optional evidence: the host-side baseline comes ahead of the profiler passes and the A/B
         # three profiler passes of one fit+predict each (+ process start): the step time is the best estimate of a pass
@@ -615,6 +660,15 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
                 out["roofline"]["traffic_over_algorithmic_c_traffic"] = live["hbm_bytes_total"] / live["algorithmic_c_traffic_bytes_total"]
             if live and live.get("mfma_util") is not None:
                 out["roofline"]["mfma_util_pmc"] = live["mfma_util"]
+        if args.nmax_n > 0:
+            # the last side measurement (the longest, ~105 s + process start): only with >= 150 s of the budget left
+            got = side("n_max", lambda: n_max_measured(args.nmax_n, args.kernel, m, args.nmax_slab, args.nmax_nb, max(30.0, remaining())), args.nmax_need_s)
+            if got:
+                out["n_max_per_gpu"] = got
+                out["vs_n"].append({"n": got["n"], "ms": got["fit_predict_s"] * 1e3, "gflops": got["gflops"], "frac_of_peak": got["frac_of_peak"],
+                                    "reps": 1, "lml": got["lml"], "jitter": got["jitter"], "note": "N_max: one COLD call, column-slab layout"})
+            elif out.get("n_max_per_gpu"):
+                out["n_max_per_gpu"]["fallback_because"] = side_errors.get("n_max", "not attempted")
         # the A/B of the never-measured optional schedules is an experiment of a builder's session (tools/gpu_session.sh), not
         # part of the default record: a kernel that hangs the GPU cannot be recovered by killing its child process
         out["experiments"] = side("experiments", lambda: schedule_experiments(max(30.0, min(150.0, remaining()))), 30.0) if args.experiments else None
@@ -784,10 +838,16 @@ def main() -> None:
     ap.add_argument("--cpu-budget-s", type=float, default=150.0)
     ap.add_argument("--no-residuals", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (steady fill, memset ceiling, N = 40 000 extra config)")
-    ap.add_argument("--side-budget-s", type=float, default=420.0,
+    ap.add_argument("--side-budget-s", type=float, default=540.0,
                     help="time budget of ALL side measurements after the timed region (steady fill, extra configuration, PMC passes, "
                          "schedule A/B); one that no longer fits is skipped and listed under side_measurement_errors")
     ap.add_argument("--extra-n", type=int, default=40000, help="size of the extra configuration measured beside the headline (BASELINE configs[1]: 40 000, the reference kernel; 0 = skip)")
+    ap.add_argument("--sweep-n", type=lambda v: [int(a) for a in v.split(",") if a], default=[4096, 8192, 16384, 32768, 65536],
+                    help="sizes below the headline of the `vs_n` curve (comma separated; empty = none)")
+    ap.add_argument("--nmax-n", type=int, default=274432, help="size of the measured N_max fit (tools/large_n.py in a child; 0 = cite profiles/r01_large_n.json only)")
+    ap.add_argument("--nmax-slab", type=int, default=2048, help="column-slab width of the N_max fit (0 = automatic)")
+    ap.add_argument("--nmax-nb", type=int, default=512, help="outer panel width of the N_max fit")
+    ap.add_argument("--nmax-need-s", type=float, default=150.0, help="side budget that must be left for the N_max fit to be started")
     ap.add_argument("--experiments", action="store_true", help="also run the A/B of the optional Cholesky schedules (tools/ab_lookahead.py) in a child process")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes of the headline workload (child processes, ~1-2 min)")
     ap.add_argument("--separate", action="store_true", help="bgp_fit then bgp_predict (separate triangular-solve pass) instead of the fused call")

@@ -218,7 +218,7 @@ def test_side_measurements_cannot_take_the_bench_record_down(tmp_path):
 
     env = dict(os.environ, BGP_ROCPROFV3=str(tmp_path / "absent"))
     cmd = [sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "bench.py", "--steps", "1", "--warmup", "0", "--size", "600",
-           "--extra-n", "500", "--cpu-n", "300", "--experiments"]
+           "--extra-n", "500", "--cpu-n", "300", "--experiments", "--sweep-n", "256,400,600,900", "--nmax-n", "1500", "--nmax-need-s", "1"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -230,6 +230,13 @@ def test_side_measurements_cannot_take_the_bench_record_down(tmp_path):
     assert [e["workload"].split(", N=")[1].split(" ")[0] for e in out["extra_configs"]] == ["500"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["phases"]) == {"fill_s", "potrf_s", "solve_predict_s"}
+    # BASELINE's "vs N" curve: the sizes below the headline, then the headline point from the timed region
+    assert [p["n"] for p in out["vs_n"]] == [256, 400, 600] and out["vs_n"][-1]["note"].startswith("the timed region")
+    assert all({"n", "ms", "gflops", "frac_of_peak", "lml"} <= set(p) and p["ms"] > 0 for p in out["vs_n"])
+    assert out["vs_n"][-1]["gflops"] == pytest.approx(out["value"]) and out["vs_n"][-1]["lml"] == out["lml"]
+    # the N_max child has no GPU here: the citation stays, labelled as one, with the reason
+    nm = out["n_max_per_gpu"]
+    assert nm["source"].startswith("CITED") and "large_n.py" in nm["fallback_because"] and "n_max" in out["side_measurement_errors"]
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
@@ -281,8 +288,10 @@ def test_side_measurements_respect_their_time_budget():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     errs = out["side_measurement_errors"]
-    assert set(errs) == {"fill_steady", "extra_300_battgp", "pmc_live", "experiments"} and all(v.startswith("skipped") for v in errs.values())
+    assert set(errs) == {"fill_steady", "extra_300_battgp", "pmc_live", "experiments", "n_max", *(f"vs_n_{v}" for v in (4096, 8192, 16384, 32768, 65536) if v < 700)}
+    assert all(v.startswith("skipped") for v in errs.values())
     assert out["extra_configs"] == [] and out["pmc_live"] is None and out["experiments"] is None
+    assert [p["n"] for p in out["vs_n"]] == [700] and out["n_max_per_gpu"]["fallback_because"].startswith("skipped")
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
@@ -330,6 +339,35 @@ def test_a_time_limit_during_the_side_measurements_still_prints_the_record(tmp_p
         except (ProcessLookupError, FileNotFoundError):
             alive = False
         assert not alive, pid
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_measured_n_max_record_is_built_from_the_large_n_child(monkeypatch):
+    """bench.n_max_measured: the child is tools/large_n.py with the slab layout given; its JSON line (produced here by the
+    same script on the CPU build, at a toy size) becomes the `n_max_per_gpu` object, labelled as measured; a failing child
+    raises (-> side_measurement_errors, the citation stays)"""
+    import subprocess
+
+    import bench
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), "tools/large_n.py", "1500", "matern32", "512", "300", "128", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    seen = {}
+
+    def fake_child(cmd, timeout, **kw):
+        seen["cmd"], seen["timeout"] = cmd, timeout
+        return subprocess.CompletedProcess(cmd, 0, r.stdout, "")
+
+    monkeypatch.setattr(bench, "run_child", fake_child)
+    rec = bench.n_max_measured(1500, "matern32", 300, 512, 128, 77.0)
+    assert seen["cmd"][1:] == [os.path.join(ROOT, "tools", "large_n.py"), "1500", "matern32", "512", "300", "128", "1"] and seen["timeout"] == 77.0
+    assert rec["n"] == 1500 and rec["slab_width"] == 512 and rec["nb_outer"] == 128 and rec["source"].startswith("measured by this run")
+    assert rec["frac_of_peak"] == pytest.approx(rec["gflops"] / 1e3 / 78.6) and rec["residuals"]["rel_solve"] < 1e-8
+    json.dumps(rec)
+    monkeypatch.setattr(bench, "run_child", lambda cmd, timeout, **kw: subprocess.CompletedProcess(cmd, 1, "", "hipErrorOutOfMemory"))
+    with pytest.raises(RuntimeError, match="hipErrorOutOfMemory"):
+        bench.n_max_measured(1500, "matern32", 300, 512, 128, 77.0)
 
 
 def test_ab_decision_tool_applies_the_rule(tmp_path):

@@ -6,7 +6,7 @@
 #       gpurun --timeout 3300 -- 'bash tools/gpu_session.sh r02 [stage ...]'
 # Everything lands under gpurun_out/<tag>s/ ; copy what is to be judged into profiles/ afterwards
 # (python tools/pmc_summary.py gpurun_out/<tag>s/pmc131k <tag> 131072 matern32).
-TAG=${1:-r04}; shift
+TAG=${1:-r05}; shift
 STAGES=${*:-"tests bench stats pmc sweep slim system train fill sharded optional"}
 REPO=$(pwd); OUT=$REPO/gpurun_out/${TAG}s; mkdir -p $OUT
 export TMPDIR=/tmp
