@@ -10,7 +10,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbattgp.so")
+# BGP_EXPERIMENTAL_LIB=1 (builder sessions only: the A/B stage of tools/gpu_session.sh, the optional parity cases) selects the
+# library built with -DBGP_EXPERIMENTAL (battgp_amd/build.py --experimental); same C-ABI, plus the untimed optional kernels
+EXPERIMENTAL = os.environ.get("BGP_EXPERIMENTAL_LIB") == "1"
+LIB_PATH = os.path.join(_HERE, "libbattgp_exp.so" if EXPERIMENTAL else "libbattgp.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -127,7 +130,7 @@ def load() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m battgp_amd.build` "
+            f"{LIB_PATH} is missing: build it with `python -m battgp_amd.build{' --experimental' if EXPERIMENTAL else ''}` "
             "(hipcc --offload-arch=gfx950).  battgp_amd has no CPU fallback."
         )
     lib = C.CDLL(LIB_PATH)
@@ -135,7 +138,7 @@ def load() -> C.CDLL:
         try:
             fn = getattr(lib, name)
         except AttributeError as exc:
-            raise ImportError(f"libbattgp.so does not export `{name}`") from exc
+            raise ImportError(f"{os.path.basename(LIB_PATH)} does not export `{name}`") from exc
         fn.restype = res
         fn.argtypes = args
     _lib = lib

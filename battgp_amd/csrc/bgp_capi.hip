@@ -393,8 +393,10 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
   // stream sb, next to rest(k) on the main stream.  Per panel the serial path loses a solve and an update over ~N rows
   // (what bounds the second half of the panels, where rest(k) is shorter than the chain).  Every element still
   // receives the same operations in the same order: bit-identical to the unsplit schedule.
-  const bool split = la && dmode && depth == 1 && (h->lookahead & 64) != 0;
-  const bool fuse = (h->lookahead & 128) != 0;
+  // (bits 5-7 exist in the experimental library only: BGP_EXP is a compile-time false in the default one, where
+  // bgp_set_options rejects them, and the split-panel blocks below are not compiled)
+  const bool split = BGP_EXP && la && dmode && depth == 1 && (h->lookahead & 64) != 0;
+  const bool fuse = BGP_EXP && (h->lookahead & 128) != 0;
   hipStream_t sb = h->s_bulk;
   if (split) {  // sb must not start before the caller's work on st either
     BGP_HIP(h, hipStreamWaitEvent(sb, ev, 0));
@@ -448,7 +450,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
       double* Akk = V.at(K0, K0);
       if ((rc = launch_diag_in(h, sp, Akk, ldk, h->dD, ldd, (int)nbk))) return rc;
       // panel 0 has no trailing update above it: nothing to fit beside
-      const bool slim = la && step > 0 && (h->lookahead & 32) != 0;
+      const bool slim = BGP_EXP && la && step > 0 && (h->lookahead & 32) != 0;
       if ((rc = factor_panel(h, sp, h->dD, 2 * nbk, ldd, inv, dinfo, 0, nbk, K0, slim, fuse))) return rc;
       // split: the bulk stream's solve of the previous panel still reads dLinv
       if (split && step > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[3 + EV_COPY * (size_t)(step - 1)], 0));
@@ -456,6 +458,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
       const int64_t rows_below = nrows - K1;
       // split: this panel's rows below the diagonal block were last written by the bulk stream's update
       if (split && step > 0 && rows_below > 0) BGP_HIP(h, hipStreamWaitEvent(sp, h->ev_sync[7 + EV_COPY * (size_t)(step - 1)], 0));
+#ifdef BGP_EXPERIMENTAL
       if (split && rows_trail > 0) {
         const int64_t nbn = (rows_trail < NB) ? rows_trail : NB, K2 = K1 + nbn;
         double* W = h->dW[step % nbuf];
@@ -481,7 +484,9 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
         if ((rc = launch_copy_panel(h, sc, W, h->ldw, V.at(K1, K0), ldk, rows_below, (int)nbk))) return rc;
         BGP_HIP(h, hipEventRecord(evC, sc));
         Wk = W;
-      } else if (rows_below > 0) {
+      } else
+#endif
+      if (rows_below > 0) {
         double* W = h->dW[step % nbuf];
         // W[step % nbuf] was the operand of panel step - nbuf: its updates on sp are ordered before us, its
         // rest() finished before the sp updates of the previous iteration started, its copy-back is waited for
@@ -505,6 +510,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
     }
     const int64_t nbn = (rows_trail < NB) ? rows_trail : NB;  // width of the next panel
     const int64_t K2 = K1 + nbn;
+#ifdef BGP_EXPERIMENTAL
     if (split) {
       const Src& p = src[step];
       const int tmode = tmode_of(nbk);
@@ -533,6 +539,7 @@ int potrf_driver(bgp_handle* h, hipStream_t st, const SlabView& V, int64_t n, in
       BGP_HIP(h, hipEventRecord(ev, st));
       continue;
     }
+#endif
     if (!la_first) {  // panel(k) complete -> rest(k) may start on st
       if ((rc = step_event(step, 1, &ev))) return rc;
       BGP_HIP(h, hipEventRecord(ev, sp));
@@ -1284,6 +1291,9 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp) {
 
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead) {
   if (!h) return -1;
+  if (!BGP_EXP && lookahead >= 0 && (lookahead & (32 | 64 | 128)))
+    return bgp_fail(h, -1, "lookahead bits 5-7 (slim chain kernels, split panels, fused update + tile Cholesky) are not in this "
+                           "library: they exist in the experimental build only (battgp_amd/build.py --experimental)");
   if (nb_outer >= 0) {
     if (nb_outer < 64 || (nb_outer % 64) != 0 || nb_outer > 2048)
       return bgp_fail(h, -1, "nb_outer must be a multiple of 64 in [64, 2048]");
@@ -1790,7 +1800,7 @@ int bgp_factor_pack_panel_async_dev(bgp_handle* h, double* panel_dev, int64_t ld
   // tile inverses are indexed by the panel-local tile (inv_dev belongs to this panel); the failing minor globally
   if ((rc = launch_diag_in(h, st, panel_dev, ld, h->dD, ldd, nbk))) return rc;
   // global report offset, panel-local inverses; lookahead bit 7: update + next tile Cholesky in one launch
-  if ((rc = factor_panel(h, st, h->dD, 2 * (int64_t)nbk, ldd, inv_dev, h->dinfo, 0, nbk, gofs, false, (h->lookahead & 128) != 0, 0)))
+  if ((rc = factor_panel(h, st, h->dD, 2 * (int64_t)nbk, ldd, inv_dev, h->dinfo, 0, nbk, gofs, false, BGP_EXP && (h->lookahead & 128) != 0, 0)))
     return rc;
   if ((rc = launch_diag_out(h, st, h->dD, ldd, panel_dev, ld, h->dLinv, NB, nbk))) return rc;
   if ((rc = launch_copy_panel(h, st, panel_dev, ld, pack_dev, nrows, nbk, nbk))) return rc;

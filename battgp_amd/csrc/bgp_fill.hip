@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256) void fill_kernel(FillParams p, const double* _
 #include "bgp_fill_tile.inc"
 }
 
+#ifdef BGP_EXPERIMENTAL
 // the matrix-pipe variant (fill_interior_mfma): two workgroups per CU by contract, so that the register budget is 256
 // and the MFMA results land in ordinary VGPRs (with the default budget of 512 the compiler parks them in AGPRs and pays
 // two v_accvgpr_read per entry - the instructions the variant exists to save)
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void fill_mfma_kernel(FillParams p, const d
   constexpr int DT = 4;
 #include "bgp_fill_tile.inc"
 }
+#endif  // BGP_EXPERIMENTAL
 
 template <int KID>
 int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t n1, const double* x2,
@@ -419,8 +421,9 @@ int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t
   // columns per thread and pass, measured at N = 131 072 (steady GB/s for 2 / 4 / 8 / 16): K0 5810 / 5750 / 5640 / 5780,
   // Matern 5440 / 5570 / 5440 / 5470 - the winners are compiled in, the sweep's other instantiations and its knob are gone
   constexpr int UNR_DEFAULT = (KID == BGP_KERNEL_BATTGP) ? 2 : 4;
-  static const bool t256 = getenv("BGP_FILL_TABLE") && atoi(getenv("BGP_FILL_TABLE")) == 256;  // experiment knob (A/B pending)
-  static const bool fmfma = getenv("BGP_FILL_MFMA") && atoi(getenv("BGP_FILL_MFMA")) == 1;  // experiment knob (A/B pending)
+#ifdef BGP_EXPERIMENTAL  // the two interior variants and their environment knobs: experimental library only (A/B pending)
+  static const bool t256 = getenv("BGP_FILL_TABLE") && atoi(getenv("BGP_FILL_TABLE")) == 256;
+  static const bool fmfma = getenv("BGP_FILL_MFMA") && atoi(getenv("BGP_FILL_MFMA")) == 1;
   if (p.D == 4 && fmfma && t256)
     hipLaunchKernelGGL((fill_mfma_kernel<KID, 12, UNR_DEFAULT>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag,
                        nv1, nv2, nti, ntj, vec_ok);
@@ -430,7 +433,9 @@ int fill_dispatch(hipStream_t st, const FillParams& p, const double* x1, int64_t
   else if (p.D == 4 && t256)
     hipLaunchKernelGGL((fill_kernel<KID, 4, 4, UNR_DEFAULT>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower, add_diag,
                        nv1, nv2, nti, ntj, vec_ok);
-  else if (p.D == 4) FILL_UNR(UNR_DEFAULT);
+  else
+#endif
+  if (p.D == 4) FILL_UNR(UNR_DEFAULT);
   else
     hipLaunchKernelGGL((fill_kernel<KID, 0>), grid, block, 0, st, p, x1, n1, x2, n2, out, ld, lower,
                        add_diag, nv1, nv2, nti, ntj, vec_ok);

@@ -1,6 +1,16 @@
 // Internal declarations shared by the HIP translation units of libbattgp.so (gfx950 only).
 #pragma once
 
+// -DBGP_EXPERIMENTAL (battgp_amd/build.py --experimental -> libbattgp_exp.so): also compiles the optional kernel families
+// that no MI355X has timed yet - slim chain kernels (look-ahead bit 5), split panels (bit 6), fused update + tile Cholesky
+// (bit 7), the table-256 and matrix-pipe interiors of the fill (BGP_FILL_TABLE / BGP_FILL_MFMA).  The default library
+// holds none of them: bgp_set_options rejects the three bits and the two environment knobs are not read.
+#ifdef BGP_EXPERIMENTAL
+constexpr bool BGP_EXP = true;
+#else
+constexpr bool BGP_EXP = false;
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -159,6 +169,7 @@ int launch_copy_panel(bgp_handle* h, hipStream_t st, const double* src, int64_t 
 // (<= 64 VGPRs, <= 12 KB LDS; bgp_linalg.hip "slim chain kernels"); bit-identical results
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv,
                       int* info, int col0, int slim = 0);
+// the next two exist as kernels only in the experimental library (-DBGP_EXPERIMENTAL); the default library's versions fail
 int launch_chain_update_potrf(bgp_handle* h, hipStream_t st, double* C, int64_t ldc, const double* A, int64_t lda,
                               const double* B, int64_t ldb, int64_t m, int64_t n, int lower, int* info, double* inv_next,
                               int col0_next, int slim = 0);

@@ -486,6 +486,9 @@ __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(double* __restrict__
   }
 }
 
+#ifdef BGP_EXPERIMENTAL
+// ==== EXPERIMENTAL (compiled only with -DBGP_EXPERIMENTAL, battgp_amd/build.py --experimental): the fused chain launch and
+// the slim chain kernels below have never been timed on an MI355X; they are not part of the default library ====
 // One launch for {rank-64 update of the rest of the panel block by column step j} + {tile Cholesky of step j + 1}:
 // the workgroup that updates the next diagonal tile (tile (0, 0) of the launch) goes on to factor and invert it while
 // the other workgroups finish their tiles.  The serial chain per 64 columns drops from three dependent launches
@@ -794,6 +797,8 @@ void chain_update_potrf_slim_kernel(double* C, int64_t ldc, const double* A, int
   __syncthreads();  // the tile's stores are visible to the whole workgroup; the operand stages are free
   potrf_slim_tile(C, ldc, inv_next, info, col0_next, lds, &sfail);
 }
+
+#endif  // BGP_EXPERIMENTAL
 
 // ---- explicit inverses of ALL diagonal panel blocks of a factor, in one launch ---------------------
 // Linv_all[p] (ld = NB) = inv(L_pp) for every outer panel p, from the factor's blocks and the stored 64 x 64
@@ -1227,10 +1232,14 @@ int launch_diag_in(bgp_handle* h, hipStream_t st, const double* Akk, int64_t lda
 
 int launch_diag_out(bgp_handle* h, hipStream_t st, const double* D, int64_t ldd, double* Akk, int64_t lda,
                     double* Linv, int64_t ldl, int nbk, int slim) {
+#ifdef BGP_EXPERIMENTAL
   if (slim)
     hipLaunchKernelGGL((diag_out_kernel<32>), dim3((unsigned)(nbk / 32), (unsigned)(nbk / 32)), dim3(256), 0, st, D, ldd,
                        Akk, lda, Linv, ldl, nbk);
   else
+#else
+  if (slim) return bgp_fail(h, -1, "diag_out: the slim kernels are not in this library (built without BGP_EXPERIMENTAL)");
+#endif
     hipLaunchKernelGGL((diag_out_kernel<64>), dim3((unsigned)(nbk / 64), (unsigned)(nbk / 64)), dim3(256), 0, st, D, ldd,
                        Akk, lda, Linv, ldl, nbk);
   BGP_HIP(h, hipGetLastError());
@@ -1295,14 +1304,19 @@ int launch_gemm_nt(bgp_handle* h, hipStream_t st, int mode, int tn, double* C, i
 
 int launch_potrf_tile(bgp_handle* h, hipStream_t st, double* Ajj, int64_t lda, double* inv, int* info,
                       int col0, int slim) {
+#ifdef BGP_EXPERIMENTAL
   if (slim)
     hipLaunchKernelGGL(potrf_tile_slim_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
   else
+#else
+  if (slim) return bgp_fail(h, -1, "potrf_tile: the slim kernels are not in this library (built without BGP_EXPERIMENTAL)");
+#endif
     hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, inv, info, col0);
   BGP_HIP(h, hipGetLastError());
   return 0;
 }
 
+#ifdef BGP_EXPERIMENTAL
 // rank-64 update of the rest of the panel block + tile Cholesky (and inverse) of its first diagonal tile, one launch
 int launch_chain_update_potrf(bgp_handle* h, hipStream_t st, double* C, int64_t ldc, const double* A, int64_t lda,
                               const double* B, int64_t ldb, int64_t m, int64_t n, int lower, int* info, double* inv_next,
@@ -1341,6 +1355,17 @@ int launch_chain_gemm_slim(bgp_handle* h, hipStream_t st, int mode, double* C, i
   BGP_HIP(h, hipGetLastError());
   return 0;
 }
+
+#else   // the default library has neither kernel family (bgp_set_options rejects the bits that would lead here)
+int launch_chain_update_potrf(bgp_handle* h, hipStream_t, double*, int64_t, const double*, int64_t, const double*, int64_t, int64_t, int64_t,
+                              int, int*, double*, int, int) {
+  return bgp_fail(h, -1, "chain_update_potrf: not in this library (built without BGP_EXPERIMENTAL)");
+}
+int launch_chain_gemm_slim(bgp_handle* h, hipStream_t, int, double*, int64_t, const double*, int64_t, const double*, int64_t, int64_t, int64_t,
+                           int, const int*) {
+  return bgp_fail(h, -1, "chain_gemm_slim: not in this library (built without BGP_EXPERIMENTAL)");
+}
+#endif  // BGP_EXPERIMENTAL
 
 int launch_trinv_panels(bgp_handle* h, hipStream_t st, const SlabView& L, const double* inv_tiles, double* Linv_all,
                         int64_t n, int NB) {

@@ -715,7 +715,8 @@ def schedule_experiments(limit_s: float = 150.0):
 
     cmd = [sys.executable, os.path.join(ROOT, "tools", "ab_lookahead.py"), "3", "4096", "16384", "40000"]
     try:
-        r = run_child(cmd, limit_s)
+        # the optional schedules exist in the experimental library only (battgp_amd/build.py --experimental)
+        r = run_child(cmd, limit_s, env=dict(os.environ, BGP_EXPERIMENTAL_LIB="1"))
         lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
         return {"what": "fit+predict ms by lookahead word (1 default, +32 slim chain kernels, +64 split panels, +128 fused update + tile Cholesky), panel scheme 1",
                 "rc": r.returncode, "runs": lines, "stderr_tail": r.stderr[-300:] if r.returncode else ""}

@@ -14,7 +14,8 @@ def pytest_addoption(parser):
     parser.addoption(
         "--emu", action="store_true",
         help="development aid while no GPU is at hand: run (a selection of) the -m gpu tests against the CPU build of the "
-             "kernel sources (tests/emu); tests that need torch CUDA tensors still need the GPU",
+             "kernel sources (tests/emu; BGP_EMU_EXPERIMENTAL=1: of the experimental library, for the optional-schedule cases); "
+             "spawned ranks follow (BGP_TEST_EMU=1 is exported)",
     )
     parser.addoption(
         "--emu-fault", action="append", default=[], metavar="SYMBOL",
@@ -26,6 +27,8 @@ def pytest_addoption(parser):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if config.getoption("--emu"):
+        # processes the tests spawn (the ranks of tests/test_gpu_sharded.py) must land on the CPU build too, not look for a GPU
+        os.environ["BGP_TEST_EMU"] = "1"
         sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
         from inject import fake_cuda_tensors, installed
 

@@ -14,14 +14,16 @@ if HERE not in sys.path:
 _cache: dict = {}
 
 
-def load_emu(sanitize: bool = False) -> C.CDLL:
+def load_emu(sanitize: bool = False, experimental=None) -> C.CDLL:
     import build_emu
 
     from battgp_amd import _lib
 
-    key = str(sanitize) if sanitize else "plain"
+    if experimental is None:
+        experimental = build_emu.experimental_default()
+    key = (str(sanitize) if sanitize else "plain") + ("+exp" if experimental else "")
     if key not in _cache:
-        lib = C.CDLL(build_emu.build(sanitize=sanitize))
+        lib = C.CDLL(build_emu.build(sanitize=sanitize, experimental=experimental))
         lib.hipemu_stream_sync.argtypes = [C.c_void_p]
         for name, (res, args) in _lib.SIGNATURES.items():
             fn = getattr(lib, name)  # the CPU build must export the whole C-ABI too
@@ -32,16 +34,18 @@ def load_emu(sanitize: bool = False) -> C.CDLL:
 
 
 class installed:
-    """``with installed(): ...`` - ExactGPEngine & co. talk to the CPU build inside the block."""
+    """``with installed(): ...`` - ExactGPEngine & co. talk to the CPU build inside the block.
+    ``experimental=True``: the CPU build of the experimental library (the optional kernel families); None: as the environment
+    says (BGP_EMU_EXPERIMENTAL=1), default = the product's configuration."""
 
-    def __init__(self, sanitize: bool = False):
-        self.sanitize = sanitize
+    def __init__(self, sanitize: bool = False, experimental=None):
+        self.sanitize, self.experimental = sanitize, experimental
 
     def __enter__(self):
         from battgp_amd import _lib
 
         self._saved = _lib._lib
-        _lib._lib = load_emu(self.sanitize)
+        _lib._lib = load_emu(self.sanitize, self.experimental)
         return _lib._lib
 
     def __exit__(self, *exc):
@@ -113,9 +117,12 @@ def fake_cuda_tensors():
     # and collectives) is host work here: it runs behind everything the stream already holds
     @contextlib.contextmanager
     def on_stream(s):
+        from battgp_amd import _lib
+
         ptr = getattr(s, "ptr", None)
-        if ptr and "plain" in _cache:
-            _cache["plain"].hipemu_stream_sync(ptr)
+        cur = _lib._lib  # the CPU build that is installed right now (default or experimental configuration)
+        if ptr and cur is not None and hasattr(cur, "hipemu_stream_sync"):
+            cur.hipemu_stream_sync(ptr)
         yield
 
     torch.cuda.stream = on_stream

@@ -65,7 +65,7 @@ def run_policy(lib, policy, las, ref):
 
 
 def main(argv):
-    with installed() as lib:
+    with installed(experimental=True) as lib:  # the split-panel schedule (bulk stream) is part of the sweep
         lib.hipemu_set_sched.argtypes = [C.c_char_p]
         lib.hipemu_drop_wait.argtypes = [C.c_long]
         lib.hipemu_wait_count.restype = C.c_long

@@ -270,6 +270,8 @@ def test_gpu_session_scripts_rehearsed_on_the_cpu_build(argv, expect):
     import subprocess
 
     env = dict(os.environ, BGP_ONLY="battgp")
+    if argv[0] == "tools/ab_lookahead.py":  # the A/B of the optional schedules: the experimental configuration of the CPU build
+        env["BGP_EMU_EXPERIMENTAL"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_script_emu.py"), *argv], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and expect in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -37,6 +37,16 @@ def emu():
         yield lib
 
 
+@pytest.fixture
+def emu_exp(emu):
+    """the CPU build of the EXPERIMENTAL library (-DBGP_EXPERIMENTAL: the optional kernel families that await their A/B on the
+    hardware) for the duration of ONE test; the module's other tests run on the product's configuration"""
+    from inject import installed
+
+    with installed(experimental=True) as lib:
+        yield lib
+
+
 @pytest.fixture(scope="module")
 def P(emu):
     return _load("test_gpu_parity")
@@ -55,6 +65,25 @@ def test_cpu_build_exports_the_whole_c_abi(emu):
         assert hasattr(emu, name)
     assert os.path.dirname(emu._name).endswith(os.path.join("tests", "emu", "_build"))
     assert _lib.LIB_PATH.endswith(os.path.join("battgp_amd", "libbattgp.so"))  # the product path is untouched
+
+
+def test_default_library_has_no_optional_schedules_and_says_so(emu):
+    """without -DBGP_EXPERIMENTAL the look-ahead bits 5-7 are refused (nothing else of the call is applied)
+    and the fill's environment knobs are not read; the experimental configuration accepts the same words"""
+    from battgp_amd import synthetic
+    from battgp_amd.engine import ExactGPEngine
+    from inject import installed
+
+    e = ExactGPEngine(0, synthetic.HYP_BATTGP)
+    for word in (1 | 32, 1 | 64, 1 | 128, 32 | 64 | 128):
+        with pytest.raises(RuntimeError, match="experimental build only"):
+            e.set_options(nb_outer=128, lookahead=word)
+    e.set_options(lookahead=2)  # the measured words still pass
+    e.close()
+    with installed(experimental=True):
+        e = ExactGPEngine(0, synthetic.HYP_BATTGP)
+        e.set_options(nb_outer=128, lookahead=1 | 32 | 64 | 128)
+        e.close()
 
 
 @pytest.mark.parametrize("kid", [0, 1, 2, 3])
@@ -121,10 +150,24 @@ def test_autograd_gradient_pins_through_the_kernels(emu, golden_dir, name, n):
     _load("test_gpu_grad").test_lml_gradient_matches_torch_autograd_pins(golden_dir, name, n)
 
 
-def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
-    """Several outer panels at a CPU-sized N (nb_outer = 128, N = 600): panel schemes 0 and 1, look-ahead off / depth 1 /
+@pytest.mark.parametrize("experimental", [False, True])
+def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu, experimental):
+    """(experimental: the same on the CPU build of the experimental library, with the optional look-ahead words added.)
+    Several outer panels at a CPU-sized N (nb_outer = 128, N = 600): panel schemes 0 and 1, look-ahead off / depth 1 /
     depth 2 / ordered, the column-slab layout, the in-place inverse gradient and the explicit-inverse backward solve - the code
     paths the GPU only reaches from N = 16 384 on with the default widths."""
+    from battgp_amd import synthetic
+    from battgp_amd.engine import ExactGPEngine
+    from oracle import kernels as K
+    from oracle.exact_gp import OracleGP, lml_and_grad
+
+    from inject import installed
+
+    with installed(experimental=experimental):
+        _multi_panel_body(experimental)
+
+
+def _multi_panel_body(experimental):
     from battgp_amd import synthetic
     from battgp_amd.engine import ExactGPEngine
     from oracle import kernels as K
@@ -140,7 +183,7 @@ def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
         outs = {}
         for scheme in (0, 1):
             # + 32: slim chain kernels, + 64: split panels, + 128: update + next tile Cholesky in one launch
-            las = (0, 1, 2, 9, 1 | 128) + ((1 | 32, 1 | 32 | 64, 1 | 32 | 64 | 128) if scheme == 1 else ())
+            las = (0, 1, 2, 9) + (((1 | 128,) + ((1 | 32, 1 | 32 | 64, 1 | 32 | 64 | 128) if scheme == 1 else ())) if experimental else ())
             for la in las:
                 e = ExactGPEngine(kid, hyp)
                 e.set_options(nb_outer=128, lookahead=la)
@@ -176,7 +219,7 @@ def test_multi_panel_paths_agree_bit_for_bit_and_match_the_oracle(emu):
         assert np.max(np.abs(g_s - g_ref) / np.abs(g_ref)) < 1e-7
 
 
-def test_failed_pivot_inside_the_fused_launch_walks_the_jitter_ladder(emu):
+def test_failed_pivot_inside_the_fused_launch_walks_the_jitter_ladder(emu_exp):
     """a pivot that fails inside chain_update_potrf_kernel (lookahead bit 7) must be reported like one that fails in the
     stand-alone tile kernel: same jitter rung, same LML, and NotPSD when the ladder is exhausted"""
     from battgp_amd.engine import ExactGPEngine, NotPSDError, NumericalWarning
@@ -224,17 +267,18 @@ def test_address_sanitizer_pass():
 
     import build_emu
 
-    build_emu.build(sanitize="asan")
+    build_emu.build(sanitize="asan", experimental=True)  # the experimental configuration: a superset of the product's code
     rt = build_emu.sanitizer_runtime("asan")
     if not os.path.exists(rt):
         pytest.skip("no shared AddressSanitizer runtime next to the host clang")
-    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", BGP_EMU_EXPERIMENTAL="1")
     r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "asan_workload.py")], env=env, capture_output=True, text=True, timeout=900)
     assert "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0 and "ASAN-PASS-DONE" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_stream_graph_under_adversarial_schedules(emu):
+@pytest.mark.parametrize("experimental", [False, True])
+def test_stream_graph_under_adversarial_schedules(emu, experimental):
     """The CPU build's streams as real queues (tests/emu/hipemu.cpp): every launch deferred and run in an order that
     honours only in-stream order, event waits and host synchronisation - lazily, eagerly, randomly, and with each of the
     four stream roles (main, panel, copy, bulk) in turn running as far ahead as the graph allows.  All schedules of the
@@ -244,17 +288,19 @@ def test_stream_graph_under_adversarial_schedules(emu):
     import ctypes as C
 
     import stream_graph_check as G
+    from inject import installed
 
-    emu.hipemu_set_sched.argtypes = [C.c_char_p]
-    emu.hipemu_set_sched(b"sync")
-    try:
-        ref = G.workload(1)
-        las = (0, 1, 2, 1 | 8, 1 | 32 | 64)
-        assert all(G.same(G.workload(la), ref) for la in las)
-        for policy in ("lazy", "eager", "random:3", "prio:1", "prio:6", "prio:10", "prio:15", "prio:20", "prio:23"):
-            assert G.run_policy(emu, policy, las, ref) == [], policy
-    finally:
-        emu.hipemu_set_sched(b"sync")
+    with installed(experimental=experimental) as lib:
+        lib.hipemu_set_sched.argtypes = [C.c_char_p]
+        lib.hipemu_set_sched(b"sync")
+        try:
+            ref = G.workload(1)
+            las = (1, 1 | 32 | 64) if experimental else (0, 1, 2, 1 | 8)  # the bulk stream exists for split panels only
+            assert all(G.same(G.workload(la), ref) for la in las)
+            for policy in ("lazy", "eager", "random:3", "prio:1", "prio:6", "prio:10", "prio:15", "prio:20", "prio:23"):
+                assert G.run_policy(lib, policy, las, ref) == [], policy
+        finally:
+            lib.hipemu_set_sched(b"sync")
 
 
 @pytest.mark.parametrize("world,sched", [(2, "prio:9"), (3, "lazy")])
@@ -325,7 +371,10 @@ def test_optional_interior_paths_of_the_fill():
 
     script = os.path.join(HERE, "emu", "fill_variant_check.py")
     envs = {"default": {}, "mfma": {"BGP_FILL_MFMA": "1"}, "mfma+t256": {"BGP_FILL_MFMA": "1", "BGP_FILL_TABLE": "256"}}
-    procs = {k: subprocess.Popen([sys.executable, script], env=dict(os.environ, **e), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    import build_emu
+
+    build_emu.build(experimental=True)  # once, before the children race for it
+    procs = {k: subprocess.Popen([sys.executable, script], env=dict(os.environ, BGP_EMU_EXPERIMENTAL="1", **e), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for k, e in envs.items()}
     res = {}
     for k, pr in procs.items():
@@ -350,7 +399,8 @@ def test_index_arithmetic_beyond_2_pow_32_elements():
     Cholesky driver under every look-ahead word - in seconds, without an N > 46 341 problem"""
     import subprocess
 
-    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "huge_ld_check.py")], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emu", "huge_ld_check.py")], env=dict(os.environ, BGP_EMU_EXPERIMENTAL="1"),
+                       capture_output=True, text=True, timeout=900)  # experimental configuration: the optional look-ahead words too
     assert r.returncode == 0 and "ok: index arithmetic beyond 2^32 elements" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 

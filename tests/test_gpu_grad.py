@@ -4,7 +4,8 @@ pass; the computation behind ``loss.backward()`` at /root/reference/src/gp/train
 Every `-m gpu` test that calls ``lml_grad`` on the single-GPU engine lives HERE, and tests/conftest.py::GPU_ORDER
 places this module after the fit / predict / natural-size / slab-layout modules: the driver runs the suite with
 ``-x``, and a fault in the (younger) gradient kernels must not leave BASELINE configs 2 and 3 unreached.
-tests/test_emu_kernels.py::test_gradient_fault_cannot_cut_the_core_record_short checks that ordering by injection."""
+tests/test_cabi_and_host.py::test_gradient_tests_sit_behind_the_core_gpu_modules checks that ordering statically; the
+dynamic rehearsal is `pytest -m gpu -x --emu --emu-fault bgp_lml_grad`."""
 
 import os
 

@@ -18,9 +18,14 @@ import pytest
 # headline record.  tools/gpu_session.sh runs them in its own last stage ("optional"), after everything else of the
 # session has been written out.  When they DO run, a failure is a failure (no xfail): the stage goes red, and
 # tools/decide_ab.py reads its log and refuses to promote a variant whose parity case did not pass.
-_ASKED = os.environ.get("BGP_TEST_OPTIONAL") == "1" or "--emu" in sys.argv
+# They live in the EXPERIMENTAL library only (battgp_amd/build.py --experimental, -DBGP_EXPERIMENTAL): on the GPU the stage
+# sets BGP_EXPERIMENTAL_LIB=1 (battgp_amd/_lib.py then loads libbattgp_exp.so), under `pytest --emu` BGP_EMU_EXPERIMENTAL=1
+# selects the CPU build of the same configuration.
+_EMU = "--emu" in sys.argv
+_ASKED = (os.environ.get("BGP_EMU_EXPERIMENTAL") == "1") if _EMU else (os.environ.get("BGP_TEST_OPTIONAL") == "1" and os.environ.get("BGP_EXPERIMENTAL_LIB") == "1")
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not _ASKED, reason="optional, off-by-default schedules: run with BGP_TEST_OPTIONAL=1 (tools/gpu_session.sh stage 'optional')")]
+              pytest.mark.skipif(not _ASKED, reason="optional schedules of the experimental library: BGP_TEST_OPTIONAL=1 BGP_EXPERIMENTAL_LIB=1 on the GPU "
+                                                    "(tools/gpu_session.sh stage 'optional'), BGP_EMU_EXPERIMENTAL=1 with --emu")]
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = os.path.join(HERE, "optional_schedule_cases.py")

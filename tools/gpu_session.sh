@@ -41,6 +41,7 @@ if has sweep; then
 fi
 if has slim; then
   stamp "slim chain kernels (+32), split panels (+64), fused update + tile Cholesky (+128): A/B, scheme 1"
+  export BGP_EXPERIMENTAL_LIB=1   # the optional families live in libbattgp_exp.so only (battgp_amd/build.py --experimental)
   for la in 1 33 65 97 129 193; do
     BGP_LA=$la BGP_SCHEME=1 BGP_ONLY=battgp timeout 600 python tools/sweep_n.py 5 4096 8192 16384 24576 32768 40000 65536 > $OUT/sweep_la$la.jsonl 2>> $OUT/sweep_n.err
   done
@@ -50,6 +51,7 @@ if has slim; then
      python $REPO/tools/profile_workload.py 16384 battgp 3 > $OUT/tl16k_slim.log 2>&1)
   python tools/timeline.py $(find $OUT/tl16k_slim -name '*kernel_trace.csv' | head -1) > $OUT/tl16k_slim_summary.txt 2>&1
   gzip -f $(find $OUT/tl16k_slim -name '*kernel_trace.csv') 2>/dev/null
+  unset BGP_EXPERIMENTAL_LIB
 fi
 if has system; then
   stamp "system flow (1 pack + 8 cells)"
@@ -65,9 +67,9 @@ fi
 if has fill; then
   stamp "steady fill"
   timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate.txt 2>&1
-  BGP_FILL_TABLE=256 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_table256.txt 2>&1
-  BGP_FILL_MFMA=1 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_mfma.txt 2>&1
-  BGP_FILL_MFMA=1 BGP_FILL_TABLE=256 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_mfma_table256.txt 2>&1
+  BGP_EXPERIMENTAL_LIB=1 BGP_FILL_TABLE=256 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_table256.txt 2>&1
+  BGP_EXPERIMENTAL_LIB=1 BGP_FILL_MFMA=1 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_mfma.txt 2>&1
+  BGP_EXPERIMENTAL_LIB=1 BGP_FILL_MFMA=1 BGP_FILL_TABLE=256 timeout 300 python tools/fill_rate.py 131072 > $OUT/fill_rate_mfma_table256.txt 2>&1
 fi
 if has sharded; then
   stamp "sharded driver, single-rank proxy"
@@ -77,7 +79,7 @@ if has sharded; then
 fi
 if has optional; then
   stamp "optional schedules / fill variants through the test suite (child processes; a failure is a failure)"
-  BGP_TEST_OPTIONAL=1 timeout 1500 python -m pytest tests/test_gpu_zz_optional_schedules.py -m gpu -q -rfE > $OUT/pytest_optional.log 2>&1
+  BGP_TEST_OPTIONAL=1 BGP_EXPERIMENTAL_LIB=1 timeout 1500 python -m pytest tests/test_gpu_zz_optional_schedules.py -m gpu -q -rfE > $OUT/pytest_optional.log 2>&1
   stamp "optional rc=$? $(tail -1 $OUT/pytest_optional.log)"
 fi
 python tools/decide_ab.py $OUT > $OUT/ab_decision.txt 2>&1   # the promote / delete list of DESIGN.md section 8, from the files above

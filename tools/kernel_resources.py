@@ -7,6 +7,7 @@
 
     python tools/kernel_resources.py            -> the table
     python tools/kernel_resources.py --loops    -> + the k-loop mix of every gemm_nt_kernel instantiation
+    python tools/kernel_resources.py --experimental   -> of the library built with -DBGP_EXPERIMENTAL
 
 tests/test_kernel_static.py turns both into a gate of the CPU suite (the class of fault the CPU build of the
 kernel sources cannot see - spills, a register count that halves the occupancy, an instantiation whose main loop differs)."""
@@ -31,10 +32,10 @@ def demangle(names):
     return names
 
 
-def compile_asm(src_name: str, out_dir: str) -> str:
+def compile_asm(src_name: str, out_dir: str, defines=()) -> str:
     """gfx950 device assembly of battgp_amd/csrc/<src_name>, same flags as battgp_amd/build.py; returns its text"""
     asm = os.path.join(out_dir, src_name + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", os.path.join(CSRC, src_name), "-o", asm],
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", *defines, "--cuda-device-only", "-S", os.path.join(CSRC, src_name), "-o", asm],
                    check=True, stderr=subprocess.DEVNULL)
     return open(asm).read()
 
@@ -104,11 +105,12 @@ def loop_profile(asm_text: str, mangled: str) -> dict:
     return {"loop": c, "total": total, "loop_lines": n}
 
 
-def collect(tmp: str) -> dict:
-    """{source file: (asm text, [resource rows with 'pretty' names])} for every .hip of the product"""
+def collect(tmp: str, experimental: bool = False) -> dict:
+    """{source file: (asm text, [resource rows with 'pretty' names])} for every .hip of the product (experimental: of the
+    library built with -DBGP_EXPERIMENTAL, battgp_amd/build.py --experimental)"""
     out = {}
     for src in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
-        text = compile_asm(src, tmp)
+        text = compile_asm(src, tmp, ("-DBGP_EXPERIMENTAL",) if experimental else ())
         rows = resources(text)
         for r, dn in zip(rows, demangle([r["name"] for r in rows])):
             r["pretty"] = dn
@@ -118,7 +120,7 @@ def collect(tmp: str) -> dict:
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        data = collect(tmp)
+        data = collect(tmp, experimental="--experimental" in sys.argv)
     print(f"{'kernel':78s} {'vgpr':>5} {'agpr':>5} {'LDS B':>7} {'scratch':>7}")
     for src, (text, rows) in data.items():
         for r in rows:
