@@ -384,7 +384,12 @@ class BatteryCellGP:
             xq = xq.reshape(-1, self._train_inputs[0].shape[1])
         if self.n_devices > 1:
             gp = self._shard()
-            if not self._fitted:  # the same fused first pass over the ranks' panels (ShardedExactGP.fit_predict)
+            n_train, m = self._train_inputs[0].shape[0], xq.shape[0]
+            # the fused first pass over the ranks' panels (ShardedExactGP.fit_predict) when the variance is wanted - like the
+            # single-GPU path below - and the query block is small next to the matrix: every riding row adds a row to every
+            # panel, its broadcast and its store (M_pad x N_pad / world doubles per rank).  A large block (add_time_steps:
+            # M ~ N, battgp_full.py:86-96) or a mean-only call takes fit + the right-looking pass over the stored factor.
+            if not self._fitted and want_var and m <= max(1024, n_train // 8):
                 gp.set_hyp(self.hyp_vector())
                 xt, yt = self._train_inputs[0], self._train_targets
                 self.lml, mean, var = gp.fit_predict(xt.detach().cpu().numpy(), yt.detach().cpu().numpy(), xq.detach().cpu().numpy(),
@@ -392,8 +397,9 @@ class BatteryCellGP:
                 self.jitter = gp.jitter
                 self._fitted = True
             else:
+                self.fit()
                 mean, var = gp.predict(xq.detach().cpu().numpy(), min_var=MIN_VARIANCE)
-            return torch.as_tensor(mean, device=xq.device), torch.as_tensor(var, device=xq.device)
+            return torch.as_tensor(mean, device=xq.device), (torch.as_tensor(var, device=xq.device) if want_var else None)
         eng = self.engine()
         xt, yt = self._train_inputs[0], self._train_targets
         m = xq.shape[0]

@@ -916,10 +916,6 @@ int ensure_alpha(bgp_handle* h) {
 // loops re-fit with new hyper-parameters before every gradient anyway: src/gp/training.py:39-41).
 int ensure_factor(bgp_handle* h) {
   if (!h->factor_consumed) return 0;
-  // bookkeeping of the FIT stays what the fit measured: what is spent here is reported in its own slot
-  (void)collect_phases(h);
-  double saved[BGP_T_COUNT];
-  memcpy(saved, h->times, sizeof(saved));
   if (h->keep_valid && h->dA_keep && h->A_keep_doubles == h->A_doubles) {
     // bgp_set_keep_factor: the storage as bgp_lml_grad found it (factor, z^T row, riding rows) comes back by one copy;
     // z, alpha, the LML, the tile and panel inverses were never touched by the gradient
@@ -930,14 +926,19 @@ int ensure_factor(bgp_handle* h) {
     h->factor_consumed = false;
     return 0;
   }
+  // bookkeeping of the FIT stays what the fit measured - also when the re-run fails (a rung of the jitter ladder that no
+  // longer holds): what is spent here is reported in its own slot
+  (void)collect_phases(h);
+  double saved[BGP_T_COUNT];
+  memcpy(saved, h->times, sizeof(saved));
   const bool alpha_was_ready = h->alpha_ready;  // alpha lives in its own vector and stays what it was
-  int rc = fit_resident(h, nullptr, nullptr, 0);
-  if (rc) return rc;
-  h->alpha_ready = alpha_was_ready;
+  const int rc = fit_resident(h, nullptr, nullptr, 0);
   (void)collect_phases(h);
   const double spent = h->times[BGP_T_FILL] + h->times[BGP_T_POTRF] + h->times[BGP_T_SOLVE];
   memcpy(h->times, saved, sizeof(saved));
   h->times[BGP_T_RESTORE] = spent;
+  if (rc) return rc;
+  h->alpha_ready = alpha_was_ready;
   return 0;
 }
 
@@ -1130,6 +1131,7 @@ void reset_logical(bgp_handle* h) {
   h->panel_mode = fresh.panel_mode;
   h->slab_req = fresh.slab_req;
   h->keep_factor = fresh.keep_factor;
+  h->keep_failed_doubles = 0;
   free_keep(h);  // (a new handle holds no second factor-sized buffer)
   if (h->ld_pad != 0) {  // (a padded buffer is not what a new handle would allocate)
     free_problem(h);
@@ -1338,6 +1340,7 @@ int bgp_set_keep_factor(bgp_handle* h, int on) {
   int rc = check_handle(h);
   if (rc) return rc;
   h->keep_factor = on != 0;
+  h->keep_failed_doubles = 0;  // a new request is a new attempt
   if (!h->keep_factor) {
     if (h->s_main) (void)hipStreamSynchronize(h->s_main);
     free_keep(h);
@@ -1985,21 +1988,27 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad) {
   double* Wt2 = Wt1 + ldt * NB;
   double* Ms = Wt2 + ldt * NB;  // [NB, NB] clean lower-triangular M_kk = inv(L_kk)
   double* Mt = Ms + NB * NB;    // [NB, NB] its transpose (negated in step A)
+  PhaseTimer t(h, st, BGP_T_GRAD);  // (the save copy below is part of what a gradient costs under bgp_set_keep_factor)
   if (h->keep_factor && !h->keep_valid) {
     // opt-in (bgp_set_keep_factor): a second buffer the size of the factor's, WHEN MEMORY ALLOWS - if it does not, the
-    // call proceeds without (the factor then comes back by a re-run of the fit, as without the switch)
-    if (h->A_keep_doubles != h->A_doubles) {
+    // call proceeds without (the factor then comes back by a re-run of the fit, as without the switch).  A failed
+    // allocation is remembered for that size: an optimiser loop calls this once per iteration, and every failing attempt
+    // would repeat a factor-sized hipMalloc and empty the pool of idle handles (dev_alloc trims it before giving up)
+    if (h->A_keep_doubles != h->A_doubles && h->keep_failed_doubles != h->A_doubles) {
       free_keep(h);
       const std::string err_before = h->err;
-      if (dev_alloc(h, &h->dA_keep, h->A_doubles) == 0) h->A_keep_doubles = h->A_doubles;
-      else h->err = err_before;
+      if (dev_alloc(h, &h->dA_keep, h->A_doubles) == 0) {
+        h->A_keep_doubles = h->A_doubles;
+      } else {
+        h->err = err_before;
+        h->keep_failed_doubles = h->A_doubles;
+      }
     }
-    if (h->dA_keep) {
+    if (h->dA_keep && h->A_keep_doubles == h->A_doubles) {
       BGP_HIP(h, hipMemcpyAsync(h->dA_keep, h->dA, (size_t)h->A_doubles * sizeof(double), hipMemcpyDeviceToDevice, st));
       h->keep_valid = true;
     }
   }
-  PhaseTimer t(h, st, BGP_T_GRAD);
   h->factor_consumed = true;  // from here on the storage no longer holds a factor, whatever happens below
   // row block [K0, K0 + nbk) x columns [0, K0) of the stored triangle <-> its transpose Wt[0:K0, 0:nbk] (one launch per slab)
   auto row_block = [&](int64_t K0, int64_t nbk, double* Wt, bool out, double scale = 1.0) -> int {

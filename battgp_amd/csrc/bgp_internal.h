@@ -111,6 +111,8 @@ struct bgp_handle {
   double* dA = nullptr;      // column slabs (SlabView) of [lda, Npad] column-major, lower triangle = Sigma then L
   double* dA_keep = nullptr; // copy of dA taken by bgp_lml_grad under keep_factor (A_keep_doubles doubles, 0 = none)
   int64_t A_keep_doubles = 0;
+  int64_t keep_failed_doubles = 0;  // size (in doubles) for which the keep buffer's allocation last failed: not retried until
+                                    // the factor's size changes or bgp_set_keep_factor is called again
   double* dInv = nullptr;    // [Npad/64][64*64] inverses of the diagonal tiles of L
   double* dz = nullptr;      // [Npad] z = L^-1 y (zero in the padding)
   double* dalpha = nullptr;  // [Npad]

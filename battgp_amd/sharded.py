@@ -401,6 +401,8 @@ class ShardedExactGP:
         if eng is not None:
             self.be.sync()
             self.store = self.pbufs = self.inv = self.z = self.nbuf = self.sbuf = None
+            self.wk = self._xq_dev = self.x_dev = self.y_dev = None  # (every device buffer goes before the engine does)
+            self._shape = None
             eng.close()
             self.engine = None
 

@@ -34,6 +34,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_PROCESS_START = time.perf_counter()
 
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak (= 256 CU x 2.4 GHz x 128 flop/clk)
 PEAK_HBM_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -570,9 +571,14 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
         side_errors = {}
 
         t_side0 = time.perf_counter()
+        # the side measurements get --side-budget-s, but never more than what --wall-budget-s leaves of the WHOLE run: with the
+        # driver's --steps 20 --warmup 5 the timed region alone takes ~4.5 min at the headline size, and a caller's time limit
+        # that kills outright (SIGKILL: no chance to print) would cost the record
+        side_budget = min(args.side_budget_s, max(0.0, args.wall_budget_s - (t_side0 - T_PROCESS_START)))
+        out["side_budget_s"] = side_budget
 
         def remaining():
-            return args.side_budget_s - (time.perf_counter() - t_side0)
+            return side_budget - (time.perf_counter() - t_side0)
 
         def side(name, fn, need_s=0.0):
             """A side measurement never takes the record above down with it, and none is started once the time budget
@@ -782,6 +788,8 @@ def run_sharded(args, rank, world, local_rank, n):
             "timers_s": gp.timers(), "lml": lml, "jitter": gp.jitter, "mean_first": [float(v) for v in mean[:3]],
             "var_first": [float(v) for v in var[:3]], "scaling": "strong",
             "later_predict_s": later_s, "later_predict_vs_fused_max_rel": later_dev,
+            # what one timed step is (records of rounds <= 3 timed fit() followed by predict(): not comparable with these)
+            "flow": "fused_fit_predict",
         }
         if grad_s is not None:
             rec["lml_grad"] = {"seconds": grad_s, "tflops_per_gpu": (2.0 * n**3 / 3.0) / grad_s / 1e12 / world,
@@ -842,6 +850,8 @@ def main() -> None:
     ap.add_argument("--side-budget-s", type=float, default=540.0,
                     help="time budget of ALL side measurements after the timed region (steady fill, extra configuration, PMC passes, "
                          "schedule A/B); one that no longer fits is skipped and listed under side_measurement_errors")
+    ap.add_argument("--wall-budget-s", type=float, default=900.0,
+                    help="time budget of the WHOLE run: the side measurements only get what the warm-up and the timed steps have left of it")
     ap.add_argument("--extra-n", type=int, default=40000, help="size of the extra configuration measured beside the headline (BASELINE configs[1]: 40 000, the reference kernel; 0 = skip)")
     ap.add_argument("--sweep-n", type=lambda v: [int(a) for a in v.split(",") if a], default=[4096, 8192, 16384, 32768, 65536],
                     help="sizes below the headline of the `vs_n` curve (comma separated; empty = none)")

@@ -63,10 +63,12 @@ enum {
   BGP_T_FILL_BYTES = 9, /* algorithmic bytes written by the last training fill */
   BGP_T_TRAIL_LAUNCHES = 10, /* number of those trailing-update launches */
   BGP_T_TRAIL_UNION = 11, /* time during which at least one of them was running (they overlap on two streams) */
-  BGP_T_GRAD = 12,    /* bgp_lml_grad: Sigma^-1 in place over the factor + the fused reduction pass */
+  BGP_T_GRAD = 12,    /* bgp_lml_grad: Sigma^-1 in place over the factor + the fused reduction pass (+ the copy that saves
+                         the factor first, under bgp_set_keep_factor) */
   BGP_T_RESTORE = 13, /* the most recent bringing-back of the factor after a gradient consumed it (copy under
                          bgp_set_keep_factor, else a re-run of the fit on the resident data); 0 = none since the last fit.
-                         The fit's own FILL / POTRF / SOLVE / TRAIL* slots are NOT touched by that re-run */
+                         The fit's own FILL / POTRF / SOLVE / TRAIL* slots are NOT touched by that re-run, whether
+                         it succeeds or fails */
   BGP_T_COUNT = 14
 };
 
@@ -187,7 +189,8 @@ int bgp_lml_grad(bgp_handle* h, double* grad_out, int ngrad);
  * factor copies it back instead of re-running the N^3/3 fit: a prediction at the optimum after
  * train_hyperparameters (src/batt_models/battcellgp_full.py:127-166 followed by :168-195) costs no second
  * factorisation.  "When memory allows": if the second buffer can not be allocated the gradient proceeds without it and
- * the factor comes back by the re-run, exactly as with the switch off (default).  on = 0 frees the buffer. */
+ * the factor comes back by the re-run, exactly as with the switch off (default); the failed allocation is not attempted
+ * again for a factor of that size until this function is called again.  on = 0 frees the buffer. */
 int bgp_set_keep_factor(bgp_handle* h, int on);
 
 /* PREDICT: posterior of the latent f at Xq[M,D] (no noise added):

@@ -128,6 +128,8 @@ static inline hipError_t hipMalloc(void** p, size_t bytes) {
   // container) fail the same way here
   const char* lim = getenv("HIPEMU_MEM_GB");
   if (bytes > ((size_t)(lim ? atoi(lim) : 6) << 30)) return hipErrorOutOfMemory;
+  const char* lim_mb = getenv("HIPEMU_MEM_MB");  // the same bound in MiB (read per call: a test can move it between two calls)
+  if (lim_mb && bytes > ((size_t)atoi(lim_mb) << 20)) return hipErrorOutOfMemory;
   if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
   // fresh device memory is NOT zero: 0xA5 bytes (a finite -1e-128 in fp64) by default; HIPEMU_POISON=ff makes every
   // never-written double a NaN, so that anything that lets a don't-care entry reach a result shows up at once

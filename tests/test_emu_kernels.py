@@ -135,7 +135,45 @@ def test_gradient_bookkeeping(emu):
     same module needs torch "device" tensors and runs under `pytest --emu` / on the GPU)"""
     G = _load("test_gpu_grad")
     G.test_restoring_the_factor_does_not_overwrite_the_fits_phase_times()
+    G.test_a_failed_restoring_fit_leaves_the_fits_phase_times_alone()
     G.test_keep_factor_brings_the_factor_back_by_a_copy(512)
+
+
+def test_a_keep_buffer_that_does_not_fit_is_not_asked_for_again(emu, monkeypatch):
+    """bgp_set_keep_factor "when memory allows" - when the second factor-sized buffer can not be allocated the
+    gradient proceeds without it AND remembers: an optimiser loop (one bgp_lml_grad per iteration) must not repeat a failing
+    factor-sized hipMalloc (which also empties the pool of idle handles) every time.  The CPU build's device refuses
+    allocations above HIPEMU_MEM_MB; once the bound is lifted the memo still holds, until the switch is set again."""
+    from battgp_amd import synthetic
+    from battgp_amd.engine import ExactGPEngine
+    from oracle import kernels as K
+
+    x, y = synthetic.make_cell_data(1500, seed=5)
+    xq = synthetic.make_query(x, 20)
+    e = ExactGPEngine(K.KERNEL_BATTGP, synthetic.HYP_BATTGP)
+    try:
+        e.fit(x, y)
+        m0, _ = e.predict(xq)
+        g0 = e.lml_grad()
+        e.predict(xq)
+        base, factor_bytes = e.device_bytes(), e.layout()[1]
+        e.set_keep_factor(True)
+        monkeypatch.setenv("HIPEMU_MEM_MB", str(int(factor_bytes / 2**20) - 1))  # the factor-sized buffer no longer fits
+        g1 = e.lml_grad()
+        assert e.device_bytes() == base and np.array_equal(g0, g1)
+        m1, _ = e.predict(xq)  # the factor comes back by the re-run, as without the switch
+        assert np.array_equal(m0, m1) and e.phase_times()["restore_ms"] > 0.0
+        monkeypatch.delenv("HIPEMU_MEM_MB")
+        e.lml_grad()
+        assert e.device_bytes() == base  # remembered: not attempted again for a factor of this size
+        e.predict(xq)
+        e.set_keep_factor(True)  # a new request is a new attempt
+        e.lml_grad()
+        assert e.device_bytes() - base == factor_bytes
+        m2, _ = e.predict(xq)
+        assert np.array_equal(m0, m2)
+    finally:
+        e.close()
 
 
 @pytest.mark.parametrize("name,n", [("k2", 400), ("k2b", 64), ("k3", 64), ("k1", 10)])

@@ -232,6 +232,42 @@ def test_restoring_the_factor_does_not_overwrite_the_fits_phase_times():
         assert t_after[k] == t_fit[k], k
 
 
+def test_a_failed_restoring_fit_leaves_the_fits_phase_times_alone():
+    """when the re-run that brings the factor back FAILS (here: the jitter rung the fit needed is no longer
+    allowed), the fit's FILL / POTRF / TRAIL* slots still hold what the caller's fit measured, the failed attempt is in
+    restore_ms, and the model recovers with the next fit."""
+    from battgp_amd.engine import NotPSDError, NumericalWarning
+
+    rng = np.random.default_rng(5)
+    n = 300
+    x = rng.normal(size=(n, 2))
+    x[150:] = x[:150]  # every point twice and no noise: singular without jitter
+    y = rng.normal(size=n)
+    hyp = np.array([0.0, 1.0, 1.0, 1.0])
+    e = ExactGPEngine(K.KERNEL_ARD_RBF, hyp)
+    try:
+        e.set_options(nb_outer=128)
+        with pytest.warns(NumericalWarning):
+            e.fit(x, y)
+        assert e.jitter > 0.0
+        t_fit = e.phase_times()
+        e.lml_grad()  # consumes the factor
+        e.set_options(max_tries=0)  # the plain attempt only: the restoring re-run can not succeed
+        with pytest.raises(NotPSDError):
+            e.predict(x[:5])
+        t_after = e.phase_times()
+        for k in ("fill_ms", "potrf_ms", "trail_ms", "trail_flop", "fill_bytes", "trail_launches", "trail_union_ms", "h2d_ms"):
+            assert t_after[k] == t_fit[k], k
+        assert t_after["restore_ms"] > 0.0
+        e.set_options(max_tries=3)
+        with pytest.warns(NumericalWarning):
+            e.fit(x, y)
+        mean, _ = e.predict(x[:5])
+        assert np.all(np.isfinite(mean))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("slab", [-1, 512])
 def test_keep_factor_brings_the_factor_back_by_a_copy(slab):
     """bgp_set_keep_factor: same gradient, same posterior bit for bit, one more factor-sized buffer while it is on."""

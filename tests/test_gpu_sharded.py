@@ -358,6 +358,23 @@ def _plugin_worker(rank, world, port, n, q):
     cell = BatteryCellGP_Full(x, y, cellnr=3, n_devices=world, device=0)  # the reference's multi-GPU switch
     t = np.linspace(x[0, 0], x[-1, 0], 40)
     df = cell.predict_r0_op(Op(*synthetic.REF_OP), t)
+    assert "fit_predict_s" in cell.model._shard().timers()  # first call, variance wanted, 40 queries: the fused pass
+    # a mean-only first call and a query block that is large next to the matrix do NOT ride through the panels
+    # (fit, then the right-looking pass over the stored factor) - same numbers
+    xq40 = np.column_stack((t, *(np.full(40, v) for v in synthetic.REF_OP)))
+    c2 = BatteryCellGP_Full(x, y, cellnr=5, n_devices=world, device=0)
+    mean_only = c2.model.posterior_mean(xq40)
+    assert "fit_predict_s" not in c2.model._shard().timers() and c2.model._shard().lay.ride == 0
+    assert np.linalg.norm(mean_only - df["r0_acausal_c3"].to_numpy()) < 1e-9 * np.linalg.norm(mean_only)
+    del c2.model
+    tb = np.linspace(x[0, 0], x[-1, 0] + 30.0, 1100)  # M > max(1024, N / 8): battgp_full.py:86-96's add_time_steps shape
+    xqb = np.column_stack((tb, *(np.full(1100, v) for v in synthetic.REF_OP)))
+    c3 = BatteryCellGP_Full(x, y, cellnr=6, n_devices=world, device=0)
+    mb, vb = c3.model.posterior(xqb)
+    assert "fit_predict_s" not in c3.model._shard().timers() and c3.model._shard().lay.ride == 0
+    mb_ref, vb_ref = cell.model.posterior(xqb)  # the fitted model's later prediction
+    assert np.allclose(mb.numpy(), mb_ref.numpy(), rtol=1e-9, atol=0) and np.allclose(vb.numpy(), vb_ref.numpy(), rtol=1e-7, atol=1e-12 * synthetic.OUTPUTSCALE_RBF)
+    del c3.model
     loss = cell.model.neg_mll() * n
     loss2, raw_grad = cell.model.neg_mll_and_raw_grad()  # analytic, sharded: what loss.backward() gives the reference
     assert loss2 * n == loss
