@@ -116,8 +116,10 @@ int bgp_set_kernel(bgp_handle* h, int kernel_id, const double* hyp, int nhyp);
  *                    the panel stream, the tall rest runs on a fourth stream (depth 1, panel scheme 1); +128: the
  *                    rank-64 update of a 64-column chain step and the tile Cholesky of the next step share one launch
  *                    (two dependent launches per 64 columns instead of three).
- *                    Bit-identical results for all (+32 / +64 / +128: shown on the CPU build of the kernel sources;
- *                    written while no GPU was available to the build, off by default until measured). */
+ *                    Bit-identical results for all.  +32 / +64 / +128 exist in the EXPERIMENTAL library only
+ *                    (libbattgp_exp.so, built with -DBGP_EXPERIMENTAL: written while no GPU was available to the build,
+ *                    bit-identity shown on the CPU build of the kernel sources, never timed); the default library
+ *                    returns -1 for a word that has one of them set and applies nothing of the call. */
 int bgp_set_options(bgp_handle* h, int nb_outer, int max_tries, double jitter0, int lookahead);
 
 /* Panel scheme of the blocked Cholesky (speed only; both are exact-Cholesky algebra).
