@@ -565,6 +565,10 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
         }
     wl.eng.close()  # frees (or parks) the factor before the scratch-sized side measurements
     _STATE["out"] = out  # from here on a SIGTERM prints the record (rank 0) instead of losing it
+    if out is not None:
+        # ... and a SIGKILL (a caller's hard time limit) during the side measurements still leaves the timed region on
+        # STDERR (stdout carries exactly one JSON line, at the end)
+        print("bench.py: timed region done, side measurements follow; record so far: " + json.dumps(out), file=sys.stderr, flush=True)
     if rank == 0 and world == 1 and not args.no_extras:
         from battgp_amd.engine import trim_pool
 
