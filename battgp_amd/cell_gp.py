@@ -388,7 +388,9 @@ class BatteryCellGP:
             # the fused first pass over the ranks' panels (ShardedExactGP.fit_predict) when the variance is wanted - like the
             # single-GPU path below - and the query block is small next to the matrix: every riding row adds a row to every
             # panel, its broadcast and its store (M_pad x N_pad / world doubles per rank).  A large block (add_time_steps:
-            # M ~ N, battgp_full.py:86-96) or a mean-only call takes fit + the right-looking pass over the stored factor.
+            # M ~ N, battgp_full.py:86-96) or a mean-only call takes fit + the right-looking passes over the stored factor
+            # (ShardedExactGP.predict: blocks of 4096 query rows, so its accumulator stays 4096 x N_pad per rank; the mean
+            # needs the same triangular solve as the variance there - z = L^-1 y is what the sharded fit keeps, not alpha).
             if not self._fitted and want_var and m <= max(1024, n_train // 8):
                 gp.set_hyp(self.hyp_vector())
                 xt, yt = self._train_inputs[0], self._train_targets

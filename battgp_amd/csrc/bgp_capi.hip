@@ -932,6 +932,9 @@ int ensure_factor(bgp_handle* h) {
   double saved[BGP_T_COUNT];
   memcpy(saved, h->times, sizeof(saved));
   const bool alpha_was_ready = h->alpha_ready;  // alpha lives in its own vector and stays what it was
+  // fit_resident resets the slots of the phases it reaches only: a re-run that fails inside the factorisation never gets to
+  // the solve, whose slot would still hold the ORIGINAL fit's time and be counted as spent here
+  h->times[BGP_T_SOLVE] = 0.0;
   const int rc = fit_resident(h, nullptr, nullptr, 0);
   (void)collect_phases(h);
   const double spent = h->times[BGP_T_FILL] + h->times[BGP_T_POTRF] + h->times[BGP_T_SOLVE];

@@ -578,21 +578,36 @@ class ShardedExactGP:
             be.update_panels(self.store, [item(j) for j in todo], cur, rows, nbk, flag_idx)
 
     # ---- predict ----------------------------------------------------------------------------------
+    PREDICT_ROWS = 4096  # query rows per right-looking pass of predict()
+
     def predict(self, xq: np.ndarray, min_var: float = 1e-10):
         """(mean, var) of the latent f at xq, identical on every rank.
 
         Right-looking over the panels with a ONE-STEP LOOK-AHEAD on the exchange, like the factorisation: at step k the
         owner solves ``E_k``, applies it to the columns of panel k+1 FIRST, the reduce of block k+1 to its owner starts
-        (asynchronously, on the communicator's stream), and the owner's update of all later columns runs underneath it."""
+        (asynchronously, on the communicator's stream), and the owner's update of all later columns runs underneath it.
+
+        The pass keeps an ``M_pad x N_pad`` accumulator on EVERY rank, so the queries go through in blocks of
+        ``PREDICT_ROWS`` rows: 8.6 GB per rank at N = 262 144 whatever M is - the ``add_time_steps`` shape (M ~ N,
+        ``src/batt_models/battgp_full.py:86-96``) would otherwise ask every rank for a second N x N buffer."""
         if self.lml is None:
             raise RuntimeError("predict: fit first (set_hyp() leaves the model unfitted)")
         t_start = time.perf_counter()
-        lay, be = self.lay, self.be
         if self._factor_consumed:  # same data, same hyper-parameters, same ladder: the factor comes back as it was
             self._phase = "fit"
             self._fit_resident()
         self._phase = "predict"
         xq = np.ascontiguousarray(xq, dtype=np.float64)
+        step = max(16, int(self.PREDICT_ROWS))
+        parts = [self._predict_block(xq[r0 : r0 + step], min_var) for r0 in range(0, max(1, xq.shape[0]), step)]
+        mean = np.concatenate([p[0] for p in parts])
+        var = np.concatenate([p[1] for p in parts])
+        self._times["predict_s"] = time.perf_counter() - t_start
+        return mean, var
+
+    def _predict_block(self, xq: np.ndarray, min_var: float):
+        """one right-looking pass for a block of query rows (see :meth:`predict`)"""
+        lay, be = self.lay, self.be
         m = xq.shape[0]
         mpad = round_up(m, 16)
         lde = mpad
@@ -638,7 +653,6 @@ class ShardedExactGP:
         self._allreduce(var_p)
         mean = be.to_host(mean_p)[:m]
         var = be.to_host(be.var_finish(xq_dev, m, self.d, var_p, min_var))[:m]
-        self._times["predict_s"] = time.perf_counter() - t_start
         return mean, var
 
     # ---- gradient ---------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ T_PROCESS_START = time.perf_counter()
 
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak (= 256 CU x 2.4 GHz x 128 flop/clk)
 PEAK_HBM_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PROFILE_TAG = "r05"  # profiles/<tag>_n<N>_<kernel>_summary.json: committed rocprofv3 PMC passes of this round
+PROFILE_TAG = "r06"  # profiles/<tag>_n<N>_<kernel>_summary.json: committed rocprofv3 PMC passes of this round
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -98,6 +98,11 @@ def _on_term(signum, _frame):
 def algorithmic_flop(n: int, m: int) -> float:
     """N^3/3 (Cholesky) + N^2 M (predictive TRSM) + 2 N^2 (two TRSV)."""
     return n**3 / 3.0 + float(n) * n * m + 2.0 * n * n
+
+
+def vs_n_need_s(n: int, m: int) -> float:
+    """side budget one point of the "vs N" curve must find left: four steps at 40 TFLOP/s + 3 s (allocation, data)"""
+    return 4.0 * algorithmic_flop(n, m) / 40e12 + 3.0
 
 
 def kernel_setup(name: str):
@@ -328,6 +333,30 @@ def profile_summary(n: int, kernel: str):
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     return json.load(f), name
     return None, None
+
+
+def n_max_need_bytes(n: int, m: int, slab: int, nb: int) -> float:
+    """Device memory of ONE fit+predict in the column-slab layout (bgp_capi.hip alloc_problem / choose_slab_width):
+    ~4 lda (Npad + W) bytes of factor, two solved-panel buffers of the panel scheme, inputs and solve vectors, runtime.
+    Held against profiles/r01_large_n.json: N = 274 432, W = 2048, nb = 512 -> 306.76 GB measured, 306.80 here;
+    N = 262 144, W = 16 384, nb = 512 -> 293.01 GB measured, 295.26 here (wide slabs: an over-estimate, the safe side)."""
+    npad = (n + 63) // 64 * 64
+    lda = npad + 64 + (m + 63) // 64 * 64
+    w = slab if slab > 0 else 16384
+    return 4.0 * lda * (npad + w) + 2.0 * lda * nb * 8.0 + 80.0 * n + 0.6e9
+
+
+def n_max_size_for(free_b: float, n_req: int, m: int, slab: int, nb: int, margin_b: float = 3e9, floor_n: int = 196608) -> int:
+    """Largest N <= n_req (steps of 4096 - a whole number of panels at every width in use) whose fit leaves `margin_b` of the
+    HBM that is free NOW: the parent process keeps its HIP context while the child runs (at N = 274 432 the
+    child needs 306.76 of the 308.56 GB an empty GPU has).  0 when not even `floor_n` (the full-square ceiling) fits."""
+    n = int(n_req)
+    floor_n = min(floor_n, n)  # (a request below the ceiling - the rehearsals - is taken as it is or not at all)
+    while n >= floor_n:
+        if n_max_need_bytes(n, m, slab, nb) + margin_b <= free_b:
+            return n
+        n -= 4096
+    return 0
 
 
 def n_max_measured(n_max: int, kernel: str, m: int, slab: int, nb: int, limit_s: float) -> dict:
@@ -646,9 +675,10 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
         extras = [side(f"extra_{en}_{ek}", lambda en=en, ek=ek: extra_config(en, ek), 10.0)
                   for en, ek in ((args.extra_n, "battgp"),) if en > 0 and not (en == n and ek == args.kernel)]
         out["extra_configs"] = [e for e in extras if e]
-        # BASELINE's metric is "... vs N": the curve below the headline size (~2 s of GPU time in all), the headline point from
-        # the timed region itself, N_max appended further down when it was measured
-        pts = [side(f"vs_n_{sn}", lambda sn=sn: sweep_point(sn), 5.0) for sn in args.sweep_n if 0 < sn < n]
+        # BASELINE's metric is "... vs N": the curve below the headline size, the headline point from the timed region itself,
+        # N_max appended further down when it was measured.  A point = one cold call (hipMalloc of the factor) + 3-5 warm
+        # steps: ~4 steps at >= 40 TFLOP/s + 3 s of set-up (N = 65 536: ~12 s; the five default points ~20 s in all)
+        pts = [side(f"vs_n_{sn}", lambda sn=sn: sweep_point(sn), vs_n_need_s(sn, m)) for sn in args.sweep_n if 0 < sn < n]
         gf0 = flop * args.steps / elapsed / 1e9
         out["vs_n"] = [p for p in pts if p] + [{"n": n, "ms": elapsed / args.steps * 1e3, "gflops": gf0, "frac_of_peak": gf0 / 1e3 / PEAK_FP64_MFMA_TFLOPS,
                                                  "reps": args.steps, "potrf_ms": rec["phases_ms"]["potrf_ms"], "fill_ms": rec["phases_ms"]["fill_ms"],
@@ -659,7 +689,8 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
         pass_s = 3.0 * (elapsed / args.steps) + 30.0
         # the first CPU sample is a required field; the second (N = 40 000) is optional and only gets what the side budget
         # has left once the profiler passes are paid for
-        host_baseline(out, args, second_budget_s=min(args.cpu_budget_s, remaining() - (0.0 if args.no_pmc else 3.0 * pass_s) - 30.0))
+        host_baseline(out, args, second_budget_s=min(args.cpu_budget_s, remaining() - (0.0 if args.no_pmc else 3.0 * pass_s) - 30.0),
+                      limit_s=max(120.0, remaining() - 10.0))
         if not args.no_pmc:
             live = side("pmc_live", lambda: pmc_live(n, args.kernel, m, limit_s=max(60.0, min(180.0, remaining() / 3.0))), 3.0 * pass_s)
             out["pmc_live"] = live
@@ -671,14 +702,32 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
             if live and live.get("mfma_util") is not None:
                 out["roofline"]["mfma_util_pmc"] = live["mfma_util"]
         if args.nmax_n > 0:
-            # the last side measurement (the longest, ~105 s + process start): only with >= 150 s of the budget left
-            got = side("n_max", lambda: n_max_measured(args.nmax_n, args.kernel, m, args.nmax_slab, args.nmax_nb, max(30.0, remaining())), args.nmax_need_s)
+            # the last side measurement (the longest, ~105 s + process start): only with >= 150 s of the budget left.
+            # The parent lets go of what it holds first (the engines are closed; their parked buffers and torch's cached
+            # blocks are not), then the size is chosen from the HBM that is really free next to the parent's own context
+            trim_pool(local_rank)
+            free_b = None
+            try:
+                import torch
+
+                torch.cuda.empty_cache()
+                free_b = float(torch.cuda.mem_get_info(local_rank)[0])
+            except Exception as exc:  # noqa: BLE001 - the citation below stays
+                side_errors["n_max_free_hbm"] = f"{type(exc).__name__}: {exc}"[:200]
+            nmax_n = n_max_size_for(free_b, args.nmax_n, m, args.nmax_slab, args.nmax_nb) if free_b is not None else args.nmax_n
+            if nmax_n <= 0:
+                side_errors["n_max"] = f"skipped: {free_b / 1e9:.1f} GB of HBM free next to this process, not enough for N >= 196608 in slabs"
+                got = None
+            else:
+                got = side("n_max", lambda: n_max_measured(nmax_n, args.kernel, m, args.nmax_slab, args.nmax_nb, max(30.0, remaining())), args.nmax_need_s)
             if got:
+                got["hbm_free_before"], got["n_requested"] = free_b, args.nmax_n
                 out["n_max_per_gpu"] = got
                 out["vs_n"].append({"n": got["n"], "ms": got["fit_predict_s"] * 1e3, "gflops": got["gflops"], "frac_of_peak": got["frac_of_peak"],
                                     "reps": 1, "lml": got["lml"], "jitter": got["jitter"], "note": "N_max: one COLD call, column-slab layout"})
             elif out.get("n_max_per_gpu"):
                 out["n_max_per_gpu"]["fallback_because"] = side_errors.get("n_max", "not attempted")
+                out["n_max_per_gpu"]["hbm_free_before"], out["n_max_per_gpu"]["n_attempted"] = free_b, nmax_n
         # the A/B of the never-measured optional schedules is an experiment of a builder's session (tools/gpu_session.sh), not
         # part of the default record: a kernel that hangs the GPU cannot be recovered by killing its child process
         out["experiments"] = side("experiments", lambda: schedule_experiments(max(30.0, min(150.0, remaining()))), 30.0) if args.experiments else None
@@ -687,7 +736,7 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
     return out
 
 
-def host_baseline(out, args, second_budget_s=None) -> None:
+def host_baseline(out, args, second_budget_s=None, limit_s=None) -> None:
     """out["cpu_baseline"]: the oracle's dense path on this box's host cores (bounded samples), measured in a CHILD process
     (`bench.py --mode cpu_baseline`) that prints its record after every sample: a LAPACK that crashes on a large matrix
     (this image's OpenBLAS dpotrf does from N = 32 768 on) or runs away costs at most the later sample, never the GPU
@@ -699,7 +748,9 @@ def host_baseline(out, args, second_budget_s=None) -> None:
            "--cpu-n", str(args.cpu_n), "--cpu-n2", str(args.cpu_n2 if budget > 0 else 0), "--cpu-budget-s", str(budget)]
     rec, note = None, ""
     try:
-        r = run_child(cmd, budget + 240.0)
+        # the child prints its record after every finished sample: a limit that cuts the second sample off keeps the first.
+        # `limit_s` = what the caller's own time budget leaves (never below the ~2 min the first, required sample may take)
+        r = run_child(cmd, budget + 240.0 if limit_s is None else min(budget + 240.0, float(limit_s)))
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"cpu_baseline"')]
         if lines:
             rec = json.loads(lines[-1])["cpu_baseline"]

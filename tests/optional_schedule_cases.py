@@ -24,7 +24,7 @@ from oracle.exact_gp import OracleGP  # noqa: E402
 
 
 @pytest.mark.parametrize("kid", [K.KERNEL_BATTGP, K.KERNEL_MATERN32])
-@pytest.mark.parametrize("n,nb", [(700, 128), (3001, 512), (20000, 512)])
+@pytest.mark.parametrize("n,nb", [(700, 128), (3001, 512), pytest.param(20000, 512, marks=pytest.mark.gpu_sized)])
 def test_slim_chain_kernels_and_split_panels_are_bit_identical(kid, n, nb):
     """lookahead bit 5: the diagonal-block chain of every panel after the first runs on the kernels sized to fit next
     to the trailing update's workgroups (potrf_tile_slim, chain_gemm_slim, 32-wide diag_out); bit 6: the panel's solve

@@ -344,6 +344,28 @@ def test_a_time_limit_during_the_side_measurements_still_prints_the_record(tmp_p
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm host clang to build the CPU stand-in")
+def test_n_max_size_follows_the_free_hbm():
+    """ADVICE r05 (bench.py N_max child): the default request, N = 274 432 in slabs of 2048, needs 306.76 GB of the 308.56 GB an
+    EMPTY MI355X has (profiles/r01_large_n.json) - next to the parent's own HIP context it would not fit.  The size is stepped
+    down to what the free HBM holds with 3 GB to spare; the memory model is held against the two measured records."""
+    import bench
+
+    runs = {(r["n"], r["slab_width"], r["nb_outer"]): r["device_bytes"] for r in json.load(open(os.path.join(ROOT, "profiles", "r01_large_n.json")))["runs"]}
+    assert bench.n_max_need_bytes(274432, 300, 2048, 512) == pytest.approx(runs[(274432, 2048, 512)], rel=2e-3)
+    got, want = bench.n_max_need_bytes(262144, 300, 16384, 512), runs[(262144, 16384, 512)]
+    assert want <= got <= 1.01 * want  # wide slabs: over-estimated by < 1 %, the safe side
+    empty = 308556070912  # hbm_free_before of those records
+    assert bench.n_max_size_for(empty, 274432, 300, 2048, 512, margin_b=0) == 274432  # what round 1 ran, on an empty GPU
+    n = bench.n_max_size_for(empty - 1.0e9, 274432, 300, 2048, 512)  # next to a parent process holding ~1 GB
+    assert 262144 <= n < 274432 and n % 4096 == 0
+    assert bench.n_max_need_bytes(n, 300, 2048, 512) + 3e9 <= empty - 1.0e9 < bench.n_max_need_bytes(n + 4096, 300, 2048, 512) + 3e9
+    assert bench.n_max_size_for(284e9, 274432, 300, 2048, 512) == 262144   # 280.2 GB in slabs of 2048 + the margin
+    assert bench.n_max_size_for(100e9, 274432, 300, 2048, 512) == 0        # below the full-square ceiling: cite, do not measure
+    assert bench.n_max_size_for(48 << 30, 1500, 300, 512, 128) == 1500     # a rehearsal-sized request is passed through
+    # the "vs N" points ask the side budget for what they cost (ADVICE r05): N = 65 536 is ~10 s, not 5
+    assert bench.vs_n_need_s(4096, 300) < 3.1 and 10.0 < bench.vs_n_need_s(65536, 300) < 15.0
+
+
 def test_measured_n_max_record_is_built_from_the_large_n_child(monkeypatch):
     """bench.n_max_measured: the child is tools/large_n.py with the slab layout given; its JSON line (produced here by the
     same script on the CPU build, at a toy size) becomes the `n_max_per_gpu` object, labelled as measured; a failing child

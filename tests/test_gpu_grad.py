@@ -252,12 +252,16 @@ def test_a_failed_restoring_fit_leaves_the_fits_phase_times_alone():
         assert e.jitter > 0.0
         t_fit = e.phase_times()
         e.lml_grad()  # consumes the factor
+        t_grad = e.phase_times()
         e.set_options(max_tries=0)  # the plain attempt only: the restoring re-run can not succeed
         with pytest.raises(NotPSDError):
             e.predict(x[:5])
         t_after = e.phase_times()
         for k in ("fill_ms", "potrf_ms", "trail_ms", "trail_flop", "fill_bytes", "trail_launches", "trail_union_ms", "h2d_ms"):
             assert t_after[k] == t_fit[k], k
+        # the failed re-run never reaches the solve: that slot is still the gradient's alpha solve (and is not counted as spent
+        # by the re-run)
+        assert t_after["solve_ms"] == t_grad["solve_ms"]
         assert t_after["restore_ms"] > 0.0
         e.set_options(max_tries=3)
         with pytest.warns(NumericalWarning):

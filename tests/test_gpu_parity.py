@@ -466,6 +466,7 @@ def test_random_problems_match_the_oracle(prob):
     check_problem(*prob)
 
 
+@pytest.mark.gpu_sized
 def test_default_panel_width_is_chosen_by_size():
     """no explicit nb_outer: 512 below N = 32 768, 1024 from there on; results agree with an explicit 512"""
     n = 33000

@@ -153,6 +153,7 @@ def test_slab_width_must_match_the_panel_width():
     e.close()
 
 
+@pytest.mark.gpu_sized
 def test_auto_layout_switches_to_slabs_when_the_square_does_not_fit():
     """occupy HBM with a torch tensor so that an N = 20 000 square (3.2 GB + margin) no longer fits"""
     n = 20000

@@ -1,0 +1,174 @@
+"""GPU parity, BASELINE configs 4 and 5 at the NATURAL size of their workload, on the ONE GPU a test box has:
+
+* config 5 - "8-cell pack, N = 100 000 per cell, one cell per GPU": each GPU's whole job is one independent exact GP of
+  N = 100 000 with the production kernel (the reference's `BattGP_Full` builds one `BatteryCellGP_Full` per cell,
+  src/batt_models/battgp_full.py:41-60); the test runs ONE cell of that pack through the checked path.
+* config 4 - "N = 262 144, one GP over 4 GPUs" (the reference's `n_devices` switch, src/batt_models/cell_gp.py:37-47):
+  the N = 262 144 matrix itself, (i) through the single-GPU engine, whose automatic layout must fall back to column slabs
+  (the full square is 550 GB), with the sampled oracle checks of tests/natural_size.py, and (ii) through `ShardedExactGP` -
+  the engine config 4 runs on 4 GPUs - as a ONE-rank group over RCCL (every broadcast / all-reduce of the schedule goes
+  through ProcessGroupNCCL, the factor in 256 block-cyclic column panels), which must reproduce (i).
+
+What one GPU can not show - the exchange between ranks over xGMI - stays with tests/test_sharded_cpu.py (gloo, world 2-4)
+and the driver's multi-GPU run.  The same code runs at toy size on any box (and under `pytest --emu`) as a rehearsal.
+
+Ordered behind the core fit / predict / gradient / adaptor / sharded modules (tests/conftest.py GPU_ORDER): minutes of GPU
+time, and a failure here must not cut the core parity record short under `-x`."""
+
+import os
+import socket
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from battgp_amd import synthetic  # noqa: E402
+from battgp_amd.engine import trim_pool  # noqa: E402
+from oracle import kernels as K  # noqa: E402
+
+from natural_size import REL, natural_size_checks  # noqa: E402  (tests/natural_size.py)
+
+EMU = os.environ.get("BGP_TEST_EMU") == "1"
+
+
+def _sharded_world1_worker(port, n, nb, m, q):
+    """One rank of config 4's engine.  On a GPU box the group is "nccl" (= RCCL); when RCCL can not form a one-rank
+    communicator there (an environment question) the rank runs without a group and says so; the CPU build uses gloo."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BGP_FORCE_GROUP="1")
+    try:
+        backend = "nccl"
+        if os.environ.get("BGP_TEST_EMU") == "1":  # `pytest --emu`: this rank lands on the CPU build of the kernel sources too
+            sys.path.insert(0, os.path.join(root, "tests", "emu"))
+            from inject import fake_cuda_tensors, installed
+
+            fake_cuda_tensors()
+            installed().__enter__()
+            backend = "gloo"
+        import torch
+        import torch.distributed as dist
+
+        from battgp_amd import synthetic
+        from battgp_amd.sharded import make_sharded_gp
+
+        group = backend
+        if backend == "nccl":
+            try:
+                torch.cuda.set_device(0)
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+                probe = torch.ones(4, dtype=torch.float64, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001 - RCCL unusable with one rank on this box: run the engine without a group
+                group = f"none ({type(exc).__name__}: {exc})"
+                os.environ["BGP_FORCE_GROUP"] = "0"
+        x, y = synthetic.make_cell_data(n)
+        xq = synthetic.make_query(x, m)
+        free0 = torch.cuda.mem_get_info()[0]
+        gp = make_sharded_gp(0, synthetic.HYP_BATTGP, nb=nb, backend_name=backend)
+        assert (gp.dist is not None) == (not group.startswith("none"))
+        lml, mean, var = gp.fit_predict(x, y, xq, min_var=-1.0)
+        mean2, var2 = gp.predict(xq[:64], min_var=-1.0)  # the right-looking pass over the stored panels
+        q.put({"ok": True, "group": group, "lml": lml, "jitter": gp.jitter, "mean": mean.tolist(), "var": var.tolist(),
+               "mean2": mean2.tolist(), "var2": var2.tolist(), "timers": gp.timers(), "comm": gp.comm_bytes(),
+               "npanels": gp.lay.npanels, "hbm_used": free0 - torch.cuda.mem_get_info()[0]})
+        gp.close()
+        if gp.dist is not None:
+            dist.destroy_process_group()
+    except BaseException as exc:  # noqa: BLE001 - reported to the parent, which fails the test with the text
+        q.put({"ok": False, "error": f"{type(exc).__name__}: {exc}"})
+        raise
+
+
+def _config5_cell(n, **kw):
+    """one cell of the pack: the production kernel at the cell's size, full oracle-sampled checks"""
+    out, _ = natural_size_checks(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, n, **kw)
+    out["engine"].close()
+    return out
+
+
+def _config4_matrix(n, nb_sharded, limit_s, slab=0, nb=-1, **kw):
+    """(i) slab layout on the single-GPU engine with the sampled oracle checks; (ii) the sharded engine, one rank, same matrix"""
+    out, (x, y, xq, mean, var) = natural_size_checks(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, n, slab=slab, nb=nb, **kw)
+    e = out.pop("engine")
+    try:
+        width, nbytes = e.layout()
+        assert 0 < width < n, (width, "the factor of config 4's matrix must be in column slabs")
+        assert nbytes < 0.75 * 8 * n * n  # ~4 N (N + W) (0.53 of the square at N = 262 144, W = 16 384): what lets it fit one GPU
+    finally:
+        e.close()
+    trim_pool()  # the parked handle's HBM: the sharded rank below needs the GPU to itself
+    torch.cuda.empty_cache()
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_sharded_world1_worker, args=(port, n, nb_sharded, len(xq), q))
+    p.start()
+    try:
+        res = q.get(timeout=limit_s)
+    finally:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert res["ok"], res
+    assert p.exitcode == 0
+    if res["group"].startswith("none"):
+        warnings.warn(f"config 4 rehearsal ran WITHOUT a process group: {res['group']}")
+    else:
+        assert res["group"] == ("gloo" if EMU else "nccl")
+        assert res["comm"]["fit"]["broadcast"][0] == res["npanels"]  # one broadcast per panel, through the group's backend
+    assert res["jitter"] == 0.0
+    assert abs(res["lml"] - out["lml"]) <= 1e-9 * abs(out["lml"]), (res["lml"], out["lml"])
+    prior = synthetic.OUTPUTSCALE_RBF
+    for mm, vv, k in ((res["mean"], res["var"], len(xq)), (res["mean2"], res["var2"], 64)):
+        mm, vv = np.array(mm), np.array(vv)
+        assert np.linalg.norm(mm - mean[:k]) <= REL * np.linalg.norm(mean[:k])
+        assert np.max(np.abs(vv - var[:k])) <= 1e-9 * prior
+    out.update(sharded_group=res["group"], sharded_timers=res["timers"], sharded_hbm=res["hbm_used"])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# toy-size rehearsals of exactly the code above: any box, and `pytest --emu`
+# ---------------------------------------------------------------------------------------------
+def test_config5_cell_rehearsal():
+    _config5_cell(2500, m=40, nblocks=6, npairs=24, nrows_solve=8)
+
+
+@pytest.mark.timeout(600)
+def test_config4_matrix_rehearsal():
+    _config4_matrix(3000, 256, 400, slab=1024, nb=512, m=40, nblocks=6, npairs=24, nrows_solve=8)
+
+
+# ---------------------------------------------------------------------------------------------
+# natural sizes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu_sized
+def test_n100000_battgp_natural_size():
+    """BASELINE config 5's per-GPU workload: one cell, N = 100 000, production kernel (80 GB full square)."""
+    if torch.cuda.mem_get_info()[0] < 90e9:
+        pytest.skip("needs ~85 GB of free HBM")
+    _config5_cell(100000)
+
+
+@pytest.mark.gpu_sized
+@pytest.mark.timeout(1500)
+def test_n262144_one_gp_natural_size():
+    """BASELINE config 4's matrix, N = 262 144, on one GPU: column slabs chosen by the automatic layout, then the sharded
+    engine as a one-rank RCCL group.  ~280-300 GB of HBM each, one after the other."""
+    if torch.cuda.mem_get_info()[0] < 290e9:
+        pytest.skip("needs ~285 GB of free HBM (4 N^2 B of factor + panel workspaces)")
+    _config4_matrix(262144, 1024, 900)

@@ -38,7 +38,7 @@ CASES = os.path.join(HERE, "optional_schedule_cases.py")
 def test_optional_schedules_in_a_child_process(request, case, limit_s):
     cmd = [sys.executable, "-m", "pytest", f"{CASES}::{case}", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"]
     if request.config.getoption("--emu"):
-        cmd += ["--emu", "-k", "not 20000"]  # (the N = 20 000 case is sized for the GPU: hours on the CPU build)
+        cmd += ["--emu"]  # (the N = 20 000 case is marked gpu_sized: hours on the CPU build, skipped there by tests/conftest.py)
     try:
         r = subprocess.run(cmd, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=limit_s)
     except subprocess.TimeoutExpired as exc:

@@ -253,6 +253,15 @@ def _worker(rank, world, port, n, nb, q):
     comm["grad"] = gp.comm_bytes(reset=True)
     mean2, var2 = gp.predict(xq)    # ... and the next prediction gets it back
     assert np.array_equal(mean, mean2) and np.array_equal(var, var2)
+    # the query rows go through in blocks (ShardedExactGP.PREDICT_ROWS; ADVICE r5: the pass keeps an M_pad x N_pad accumulator
+    # on every rank): 21 rows as 16 + 5 - two passes, two sets of per-panel reduces - give the same posterior
+    gp.comm_bytes(reset=True)
+    gp.PREDICT_ROWS = 16
+    mean_c, var_c = gp.predict(xq)
+    gp.PREDICT_ROWS = ShardedExactGP.PREDICT_ROWS
+    assert np.allclose(mean_c, mean, rtol=1e-11, atol=0) and np.max(np.abs(var_c - var)) < 1e-12 * synthetic.OUTPUTSCALE_RBF
+    if dist is not None:
+        assert gp.comm_bytes()["predict"]["reduce"][0] == 2 * gp.lay.npanels
     gp.comm_bytes(reset=True)
     # fit + first prediction in one pass: the query rows ride through the factorisation (no right-looking pass, no reduce)
     lml_fp, mean_fp, var_fp = gp.fit_predict(x, y, xq)

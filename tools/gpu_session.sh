@@ -6,7 +6,7 @@
 #       gpurun --timeout 3300 -- 'bash tools/gpu_session.sh r02 [stage ...]'
 # Everything lands under gpurun_out/<tag>s/ ; copy what is to be judged into profiles/ afterwards
 # (python tools/pmc_summary.py gpurun_out/<tag>s/pmc131k <tag> 131072 matern32).
-TAG=${1:-r05}; shift
+TAG=${1:-r06}; shift
 STAGES=${*:-"tests bench stats pmc sweep slim system train fill sharded optional"}
 REPO=$(pwd); OUT=$REPO/gpurun_out/${TAG}s; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -20,7 +20,8 @@ if has tests; then
 fi
 if has bench; then
   stamp "bench default"
-  timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench_default.json 2> $OUT/bench_default.err
+  # bench.py's own wall budget (780 s) ends inside the stage's limit: the record is printed by bench.py, not by SIGTERM
+  timeout 1000 python bench.py --steps 3 --warmup 1 --wall-budget-s 780 > $OUT/bench_default.json 2> $OUT/bench_default.err
   stamp "bench rc=$? $(cut -c1-200 $OUT/bench_default.json)"
 fi
 if has stats; then
@@ -28,6 +29,13 @@ if has stats; then
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats131k -o st -- \
      python $REPO/bench.py --steps 1 --warmup 1 --no-extras --cpu-n 0 --no-residuals > $OUT/stats131k.log 2>&1)
   find $OUT/stats131k -name '*kernel_trace.csv' -delete   # hundreds of thousands of rows; the stats file is what is kept
+  # the ORDERED-LAUNCH pass (look-ahead word 1|8: the panel stream's updates are ordered before rest(k), so the trailing
+  # update's launches do not overlap): sum of gemm_nt_kernel<128,128,2> durations <= step time, which makes the roofline
+  # fraction recomputable from the stats file alone, without an overlap argument
+  stamp "rocprofv3 kernel stats, N = 131072 matern32, ordered launches (--lookahead 9)"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats131k_ordered -o st -- \
+     python $REPO/bench.py --steps 1 --warmup 1 --lookahead 9 --no-extras --cpu-n 0 --no-residuals > $OUT/stats131k_ordered.log 2>&1)
+  find $OUT/stats131k_ordered -name '*kernel_trace.csv' -delete
 fi
 if has pmc; then
   stamp "PMC passes, N = 131072 matern32"
