@@ -671,6 +671,14 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
             finally:
                 w.close()
 
+        # REQUIRED field before optional evidence: `cpu_baseline` (host cores only, a child process) is the first thing after
+        # the timed region - a caller's time limit that ends the side measurements early then costs optional fields only.
+        # Three profiler passes of one fit+predict each (+ process start): the step time is the best estimate of a pass.
+        pass_s = 3.0 * (elapsed / args.steps) + 30.0
+        # The first CPU sample is required; the second (N = 40 000) is optional and only gets what the side budget has left
+        # once the profiler passes and the GPU-side extras (steady fill, extra config, vs-N curve: ~60 s) are paid for
+        host_baseline(out, args, second_budget_s=min(args.cpu_budget_s, remaining() - (0.0 if args.no_pmc else 3.0 * pass_s) - 90.0),
+                      limit_s=max(120.0, remaining() - 10.0))
         side("fill_steady", fill_side, 20.0)
         extras = [side(f"extra_{en}_{ek}", lambda en=en, ek=ek: extra_config(en, ek), 10.0)
                   for en, ek in ((args.extra_n, "battgp"),) if en > 0 and not (en == n and ek == args.kernel)]
@@ -684,13 +692,6 @@ def run_cells(args, rank, world, local_rank, dist, red_dev):
                                                  "reps": args.steps, "potrf_ms": rec["phases_ms"]["potrf_ms"], "fill_ms": rec["phases_ms"]["fill_ms"],
                                                  "lml": lml, "jitter": jitter, "note": "the timed region of this run"}]
         trim_pool(local_rank)  # the children below need the HBM
-        # required field before optional evidence: the host-side baseline comes ahead of the profiler passes and the A/B
-        # three profiler passes of one fit+predict each (+ process start): the step time is the best estimate of a pass
-        pass_s = 3.0 * (elapsed / args.steps) + 30.0
-        # the first CPU sample is a required field; the second (N = 40 000) is optional and only gets what the side budget
-        # has left once the profiler passes are paid for
-        host_baseline(out, args, second_budget_s=min(args.cpu_budget_s, remaining() - (0.0 if args.no_pmc else 3.0 * pass_s) - 30.0),
-                      limit_s=max(120.0, remaining() - 10.0))
         if not args.no_pmc:
             live = side("pmc_live", lambda: pmc_live(n, args.kernel, m, limit_s=max(60.0, min(180.0, remaining() / 3.0))), 3.0 * pass_s)
             out["pmc_live"] = live

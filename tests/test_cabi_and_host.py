@@ -346,7 +346,7 @@ def test_header_is_plain_c_and_a_c_program_drives_the_abi(tmp_path):
 def test_gradient_tests_sit_behind_the_core_gpu_modules():
     """The driver runs `pytest -m gpu -x`: nothing in the modules ordered BEFORE tests/test_gpu_grad.py may reach the
     LML-gradient kernels (the youngest device code), or a fault there leaves BASELINE configs 2 and 3 unreached.
-    (The dynamic rehearsal of the same thing: `pytest -m gpu -x --emu --emu-fault bgp_lml_grad`, DESIGN.md section 8.)"""
+    (The dynamic rehearsal of the same thing: `pytest -m gpu -x --emu --emu-fault bgp_lml_grad`, DESIGN.md section 10.)"""
     import ast
 
     import conftest

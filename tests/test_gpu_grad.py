@@ -5,7 +5,7 @@ Every `-m gpu` test that calls ``lml_grad`` on the single-GPU engine lives HERE,
 places this module after the fit / predict / natural-size / slab-layout modules: the driver runs the suite with
 ``-x``, and a fault in the (younger) gradient kernels must not leave BASELINE configs 2 and 3 unreached.
 tests/test_cabi_and_host.py::test_gradient_tests_sit_behind_the_core_gpu_modules checks that ordering statically; the
-dynamic rehearsal is `pytest -m gpu -x --emu --emu-fault bgp_lml_grad` (DESIGN.md section 8)."""
+dynamic rehearsal is `pytest -m gpu -x --emu --emu-fault bgp_lml_grad` (DESIGN.md section 10)."""
 
 import os
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 from battgp_amd import synthetic  # noqa: E402
-from battgp_amd.engine import ExactGPEngine  # noqa: E402
+from battgp_amd.engine import ExactGPEngine, trim_pool  # noqa: E402
 from oracle import kernels as K  # noqa: E402
 from oracle.exact_gp import OracleGP  # noqa: E402
 
@@ -156,6 +156,8 @@ def test_n131072_matern_natural_size_and_layouts():
     """BASELINE config 3 at full size: N = 131 072, Matern-3/2 + noise; plus the column-slab layout of the same
     problem, which must reproduce LML, mean and variance bit for bit."""
     n = 131072
+    trim_pool()  # engines closed by earlier tests park their buffers (up to 40 GiB; 12.8 GB after the N = 40 000 case): not "in use"
+    torch.cuda.empty_cache()
     free_b, _ = torch.cuda.mem_get_info()
     if free_b < 150e9:
         pytest.skip("needs ~140 GB of free HBM")

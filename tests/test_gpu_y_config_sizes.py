@@ -87,6 +87,15 @@ def _sharded_world1_worker(port, n, nb, m, q):
         raise
 
 
+def _free_hbm():
+    """free HBM once this process has let go of what it merely keeps warm: engines closed by earlier tests park their
+    buffers in the handle pool (up to BGP_POOL_BYTES = 40 GiB - enough to push the N = 262 144 case under its limit),
+    torch caches freed blocks"""
+    trim_pool()
+    torch.cuda.empty_cache()
+    return torch.cuda.mem_get_info()[0]
+
+
 def _config5_cell(n, **kw):
     """one cell of the pack: the production kernel at the cell's size, full oracle-sampled checks"""
     out, _ = natural_size_checks(K.KERNEL_BATTGP, synthetic.HYP_BATTGP, n, **kw)
@@ -159,7 +168,7 @@ def test_config4_matrix_rehearsal():
 @pytest.mark.gpu_sized
 def test_n100000_battgp_natural_size():
     """BASELINE config 5's per-GPU workload: one cell, N = 100 000, production kernel (80 GB full square)."""
-    if torch.cuda.mem_get_info()[0] < 90e9:
+    if _free_hbm() < 90e9:
         pytest.skip("needs ~85 GB of free HBM")
     _config5_cell(100000)
 
@@ -169,6 +178,6 @@ def test_n100000_battgp_natural_size():
 def test_n262144_one_gp_natural_size():
     """BASELINE config 4's matrix, N = 262 144, on one GPU: column slabs chosen by the automatic layout, then the sharded
     engine as a one-rank RCCL group.  ~280-300 GB of HBM each, one after the other."""
-    if torch.cuda.mem_get_info()[0] < 290e9:
+    if _free_hbm() < 290e9:
         pytest.skip("needs ~285 GB of free HBM (4 N^2 B of factor + panel workspaces)")
     _config4_matrix(262144, 1024, 900)

@@ -1,4 +1,4 @@
-"""Turns the A/B measurements of one GPU session into the decision DESIGN.md section 8 prescribes - mechanically, so that
+"""Turns the A/B measurements of one GPU session into the decision DESIGN.md section 10.2 prescribes - mechanically, so that
 the optional variants are either promoted or deleted the day they are measured:
 
     a variant becomes the default at the sizes where it is faster than the default by MORE THAN 2 % AND (schedules: bit-identical;
@@ -151,7 +151,7 @@ def main(folder):
             promote.append(f"fill variant {tag} (best {max(gains):.3f}x; elementwise-bound test green)")
         else:
             delete.append(f"fill variant {tag}: best {max(gains):.3f}x")
-    print("== decision (DESIGN.md section 8: > 2 % faster AND inside its parity gate -> default there; otherwise deleted with its knob)")
+    print("== decision (DESIGN.md section 10.2: > 2 % faster AND inside its parity gate -> default there; otherwise deleted with its knob)")
     for title, items in (("promote", promote), ("delete", delete), ("undecided", undecided)):
         print(f"   {title}:")
         for it in items or ["(none)"]:

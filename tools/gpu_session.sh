@@ -90,6 +90,6 @@ if has optional; then
   BGP_TEST_OPTIONAL=1 BGP_EXPERIMENTAL_LIB=1 timeout 1500 python -m pytest tests/test_gpu_zz_optional_schedules.py -m gpu -q -rfE > $OUT/pytest_optional.log 2>&1
   stamp "optional rc=$? $(tail -1 $OUT/pytest_optional.log)"
 fi
-python tools/decide_ab.py $OUT > $OUT/ab_decision.txt 2>&1   # the promote / delete list of DESIGN.md section 8, from the files above
+python tools/decide_ab.py $OUT > $OUT/ab_decision.txt 2>&1   # the promote / delete list of DESIGN.md section 10.2, from the files above
 stamp done
 ls -la $OUT
