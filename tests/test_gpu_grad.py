@@ -179,6 +179,7 @@ def _gradient_vs_lml_differences(e, hyp, rel_step=2e-4, rtol=2e-3):
     return grad
 
 
+@pytest.mark.gpu_sized
 def test_n40000_gradient_at_the_natural_size():
     """BASELINE config 2's size: the in-place-inverse gradient under the automatic defaults (panel scheme 1, NB = 1024,
     full square) and in column slabs - consistent with differences of the LML, identical between the two layouts up to
